@@ -1,0 +1,291 @@
+#!/usr/bin/env python
+"""Generates the committed golden fixtures under tests/golden/ and pins the CPU oracle.
+
+Run in the BUILD CONTAINER only (it reads /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_goldens.py
+
+What it does
+  1. imports the reference's own modules from /root/reference (read-only, bytecode writes off):
+       * `aligner.wise`            directly;
+       * `aligner.loss`            with a no-op `overrides` decorator module on the path;
+       * `aligner.encoder.slip`    with inert `ftfy` / `cached_path` / `timm` modules on the path (identity functions that
+                                   are never called on the code path used here: LayerNorm, QuickGELU,
+                                   ResidualAttentionBlock, Transformer, CLIP.encode_text).
+     The stand-in modules are written to a temp dir by this script (text below is ours, not the reference's); they
+     replace no arithmetic.
+  2. builds HuggingFace `CLIPModel` from a LOCAL config (no download) as a second, independent implementation of the
+     OpenAI CLIP architecture the reference calls through the third-party `clip` package.
+  3. loads the SAME seeded synthetic weights (fitclip_amd.synth) into all of them, runs them and the oracle on the same
+     seeded inputs, asserts agreement, and stores inputs/expected outputs as small .npz fixtures + PINNING.json.
+
+Fixtures hold data only (inputs, seeds and expected outputs); weights are regenerated from the seed by `synth`.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+sys.dont_write_bytecode = True
+
+from fitclip_amd import synth  # noqa: E402
+from oracle import clip_oracle as O  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+_SHIMS = {
+    "overrides.py": "def overrides(method=None, *, check_signature=True, check_at_runtime=False):\n"
+                    "    return method if method is not None else (lambda m: m)\n",
+    "ftfy.py": "def fix_text(t):\n    return t\n",
+    "cached_path.py": "def cached_path(p, *a, **k):\n    return p\n",
+    "timm/__init__.py": "from . import models\n\n\ndef create_model(*a, **k):\n    raise RuntimeError('timm absent')\n",
+    "timm/models/__init__.py": "from . import registry, vision_transformer\n",
+    "timm/models/registry.py": "def register_model(fn):\n    return fn\n",
+    "timm/models/vision_transformer.py": "def _create_vision_transformer(*a, **k):\n"
+                                         "    raise RuntimeError('timm absent')\n",
+}
+
+
+def _import_reference():
+    shim_dir = tempfile.mkdtemp(prefix="fitclip_shims_")
+    for rel, text in _SHIMS.items():
+        p = Path(shim_dir) / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(text)
+    sys.path.insert(0, shim_dir)
+    sys.path.insert(0, REFERENCE)
+    from aligner import wise as ref_wise  # noqa
+    from aligner import loss as ref_loss  # noqa
+    from aligner.encoder import slip as ref_slip  # noqa
+    return ref_wise, ref_loss, ref_slip
+
+
+def _maxdiff(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).abs().max())
+
+
+def golden_wise(ref_wise, report) -> None:
+    class Two(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed)
+            self.a = torch.nn.Parameter(torch.randn(5, 7, generator=g))
+            self.inner = torch.nn.Linear(3, 4)
+            with torch.no_grad():
+                self.inner.weight.copy_(torch.randn(4, 3, generator=g))
+                self.inner.bias.copy_(torch.randn(4, generator=g))
+
+    m1, m2 = Two(1), Two(2)
+    out = {}
+    for w in (0.0, 0.4, 0.5, 1.0):
+        sd = ref_wise.wise_state_dict(m1, m2, weight_for_2=w)
+        mine = O.wise_state_dict(dict(m1.named_parameters()), dict(m2.named_parameters()), w)
+        for k in sd:
+            assert torch.equal(sd[k], mine[k]), k
+            out[f"w{w}_{k}"] = sd[k].detach().numpy()
+        m = ref_wise.wise(m1, m2, weight_for_2=w)
+        assert all(torch.equal(p, sd[k]) for k, p in m.named_parameters())
+    for k, p in m1.named_parameters():
+        out[f"m1_{k}"] = p.detach().numpy()
+    for k, p in m2.named_parameters():
+        out[f"m2_{k}"] = p.detach().numpy()
+    np.savez(HERE / "wise_ref.npz", **out)
+    report["wise_vs_reference_aligner.wise"] = "bit-exact (weights 0, 0.4, 0.5, 1)"
+
+
+def golden_loss(ref_loss, report) -> None:
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    worst = 0.0
+    for n, scale in ((8, 1.0), (8, 30.0), (5, 66.7)):
+        s = torch.randn(n, n, generator=g) * scale
+        t = torch.randn(n, n, generator=g) * scale
+        nce = ref_loss.NCELoss()(s)
+        kd = ref_loss.TeacherStudentNCELoss(reduction="batchmean")(s, t)
+        worst = max(worst, _maxdiff(nce, O.nce_loss(s)), _maxdiff(kd, O.teacher_student_nce_loss(s, t)))
+        tag = f"n{n}_s{scale}"
+        out[f"{tag}_scores"], out[f"{tag}_teacher"] = s.numpy(), t.numpy()
+        out[f"{tag}_nce"], out[f"{tag}_kd"] = nce.numpy(), kd.numpy()
+    assert worst < 1e-5, worst
+    np.savez(HERE / "loss_ref.npz", **out)
+    report["loss_vs_reference_aligner.loss_maxabs"] = worst
+
+
+def _slip_text_model(ref_slip, d: synth.ClipDims, sd):
+    m = ref_slip.CLIP(embed_dim=d.embed_dim, vision_width=d.vision_width, vision_model=torch.nn.Identity(),
+                      context_length=d.context_length, vocab_size=d.vocab_size,
+                      transformer_width=d.transformer_width, transformer_heads=d.transformer_heads,
+                      transformer_layers=d.transformer_layers)
+    own = {k: v for k, v in sd.items() if not k.startswith("visual.")}
+    missing, unexpected = m.load_state_dict(own, strict=False)
+    assert not unexpected, unexpected
+    assert set(missing) <= {"image_projection", "logit_scale"}, missing
+    return m.eval()
+
+
+def _slip_visual(ref_slip, d: synth.ClipDims, sd, images: torch.Tensor) -> torch.Tensor:
+    """OpenAI visual stem around the REFERENCE's own Transformer / LayerNorm classes."""
+    tr = ref_slip.Transformer(d.vision_width, d.vision_layers, d.vision_heads)
+    pre = "visual.transformer."
+    tr.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+    ln_pre, ln_post = ref_slip.LayerNorm(d.vision_width), ref_slip.LayerNorm(d.vision_width)
+    ln_pre.load_state_dict({"weight": sd["visual.ln_pre.weight"], "bias": sd["visual.ln_pre.bias"]})
+    ln_post.load_state_dict({"weight": sd["visual.ln_post.weight"], "bias": sd["visual.ln_post.bias"]})
+    x = torch.nn.functional.conv2d(images, sd["visual.conv1.weight"], stride=d.vision_patch_size)
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    x = torch.cat([sd["visual.class_embedding"].expand(x.shape[0], 1, -1), x], dim=1)
+    x = ln_pre(x + sd["visual.positional_embedding"])
+    x = tr(x.permute(1, 0, 2)).permute(1, 0, 2)  # the reference's blocks are sequence-first (slip.py:471-473)
+    return ln_post(x[:, 0, :]) @ sd["visual.proj"]
+
+
+def _hf_model(d: synth.ClipDims, sd):
+    os.environ["HF_HUB_OFFLINE"] = "1"
+    from transformers import CLIPConfig, CLIPModel
+    cfg = CLIPConfig(
+        text_config=dict(hidden_size=d.transformer_width, intermediate_size=4 * d.transformer_width,
+                         num_hidden_layers=d.transformer_layers, num_attention_heads=d.transformer_heads,
+                         max_position_embeddings=d.context_length, vocab_size=d.vocab_size, hidden_act="quick_gelu",
+                         layer_norm_eps=1e-5, eos_token_id=d.vocab_size - 1, bos_token_id=d.vocab_size - 2,
+                         pad_token_id=0, projection_dim=d.embed_dim),
+        vision_config=dict(hidden_size=d.vision_width, intermediate_size=4 * d.vision_width,
+                           num_hidden_layers=d.vision_layers, num_attention_heads=d.vision_heads,
+                           image_size=d.image_resolution, patch_size=d.vision_patch_size, hidden_act="quick_gelu",
+                           layer_norm_eps=1e-5, projection_dim=d.embed_dim),
+        projection_dim=d.embed_dim)
+    m = CLIPModel(cfg).eval()
+    hf = {}
+
+    def blocks(src: str, dst: str, layers: int, width: int) -> None:
+        for i in range(layers):
+            s, t = f"{src}.resblocks.{i}", f"{dst}.encoder.layers.{i}"
+            w, b = sd[f"{s}.attn.in_proj_weight"], sd[f"{s}.attn.in_proj_bias"]
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                hf[f"{t}.self_attn.{n}.weight"] = w[j * width:(j + 1) * width]
+                hf[f"{t}.self_attn.{n}.bias"] = b[j * width:(j + 1) * width]
+            hf[f"{t}.self_attn.out_proj.weight"] = sd[f"{s}.attn.out_proj.weight"]
+            hf[f"{t}.self_attn.out_proj.bias"] = sd[f"{s}.attn.out_proj.bias"]
+            for a, c in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2")):
+                hf[f"{t}.{c}.weight"], hf[f"{t}.{c}.bias"] = sd[f"{s}.{a}.weight"], sd[f"{s}.{a}.bias"]
+            for a, c in (("c_fc", "fc1"), ("c_proj", "fc2")):
+                hf[f"{t}.mlp.{c}.weight"], hf[f"{t}.mlp.{c}.bias"] = sd[f"{s}.mlp.{a}.weight"], sd[f"{s}.mlp.{a}.bias"]
+
+    blocks("visual.transformer", "vision_model", d.vision_layers, d.vision_width)
+    blocks("transformer", "text_model", d.transformer_layers, d.transformer_width)
+    hf["vision_model.embeddings.class_embedding"] = sd["visual.class_embedding"]
+    hf["vision_model.embeddings.patch_embedding.weight"] = sd["visual.conv1.weight"]
+    hf["vision_model.embeddings.position_embedding.weight"] = sd["visual.positional_embedding"]
+    hf["vision_model.pre_layrnorm.weight"], hf["vision_model.pre_layrnorm.bias"] = \
+        sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"]
+    hf["vision_model.post_layernorm.weight"], hf["vision_model.post_layernorm.bias"] = \
+        sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]
+    hf["visual_projection.weight"] = sd["visual.proj"].T.contiguous()
+    hf["text_model.embeddings.token_embedding.weight"] = sd["token_embedding.weight"]
+    hf["text_model.embeddings.position_embedding.weight"] = sd["positional_embedding"]
+    hf["text_model.final_layer_norm.weight"], hf["text_model.final_layer_norm.bias"] = \
+        sd["ln_final.weight"], sd["ln_final.bias"]
+    hf["text_projection.weight"] = sd["text_projection"].T.contiguous()
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in k) or k == "logit_scale" for k in missing), missing
+    return m
+
+
+def golden_towers(ref_slip, report) -> None:
+    for tag, d, n_clip, n_frames, n_text in (("tiny", synth.TINY, 4, 2, 6), ("vitb16", synth.VIT_B_16, 2, 2, 6)):
+        sd = O.to_torch(synth.make_state_dict(d, seed=42))
+        video = torch.from_numpy(synth.make_video(n_clip, n_frames, d, seed=42))
+        ids = torch.from_numpy(synth.make_text(n_text, d, seed=42))
+        ids_rand = torch.from_numpy(synth.make_text(n_text, d, seed=43, all_random=True))
+        images = video.reshape(-1, *video.shape[2:])
+        with torch.inference_mode():
+            mine_img = O.encode_image(sd, images)
+            mine_txt = O.encode_text_tokens(sd, ids)
+            mine_txt_rand = O.encode_text_tokens(sd, ids_rand)
+            slip_txt_model = _slip_text_model(ref_slip, d, sd)
+            slip_txt = slip_txt_model.encode_text(ids)
+            slip_txt_rand = slip_txt_model.encode_text(ids_rand)
+            slip_img = _slip_visual(ref_slip, d, sd, images)
+            hf = _hf_model(d, sd)
+            hf_img = hf.visual_projection(hf.vision_model(pixel_values=images).pooler_output)
+            hf_txt = hf.text_projection(hf.text_model(input_ids=ids).pooler_output)
+        scale = float(mine_img.abs().max())
+        diffs = {
+            "text_vs_reference_slip.CLIP.encode_text": _maxdiff(mine_txt, slip_txt),
+            "text_allrandom_ids_vs_reference_slip": _maxdiff(mine_txt_rand, slip_txt_rand),
+            "visual_vs_reference_slip.Transformer_blocks": _maxdiff(mine_img, slip_img),
+            "visual_vs_hf_clip": _maxdiff(mine_img, hf_img),
+            "text_vs_hf_clip": _maxdiff(mine_txt, hf_txt),
+            "output_abs_max": scale,
+        }
+        for k, v in diffs.items():
+            if k != "output_abs_max":
+                assert v < 2e-5 * max(1.0, scale), (tag, k, v)
+        report[f"towers_{tag}_maxabs"] = diffs
+        np.savez(HERE / f"towers_{tag}.npz", seed=42, n_clip=n_clip, n_frames=n_frames, n_text=n_text,
+                 ids=ids.numpy(), ids_rand=ids_rand.numpy(),
+                 image_features_slip=slip_img.numpy(), text_features_slip=slip_txt.numpy(),
+                 text_features_rand_slip=slip_txt_rand.numpy(),
+                 image_features_hf=hf_img.numpy(), text_features_hf=hf_txt.numpy(),
+                 image_features_oracle=mine_img.numpy(), text_features_oracle=mine_txt.numpy())
+
+
+def golden_evaluate(report) -> None:
+    """`command=evaluate` goldens from the oracle (BASELINE config 1: 16 x 1 frame + 16 texts; plus a tiny one)."""
+    for tag, d, n, f in (("tiny", synth.TINY, 12, 3), ("config1", synth.VIT_B_16, 16, 1)):
+        sd = O.to_torch(synth.make_state_dict(d, seed=42))
+        video = torch.from_numpy(synth.make_video(n, f, d, seed=42))
+        ids = torch.from_numpy(synth.make_text(n, d, seed=42))
+        with torch.inference_mode():
+            ev, et = O.forward(sd, video, {"input_ids": ids})
+            step = O.step_scores(ev, et, 0.015)
+            loss = O.nce_loss(step)
+            scores = O.retrieval_scores(et, ev)
+            metrics = O.retrieval_metrics(scores)
+            ranks = O.ranks_of_target(scores, torch.arange(n))
+        np.savez(HERE / f"evaluate_{tag}.npz", seed=42, n_clips=n, n_frames=f, encoded_videos=ev.numpy(),
+                 encoded_texts=et.numpy(), scores=scores.numpy(), loss_val=loss.numpy(), ranks=ranks.numpy(),
+                 **{k: np.float64(v) for k, v in metrics.items()})
+        report[f"evaluate_{tag}"] = {"loss/val": float(loss), **metrics}
+
+
+def golden_wise_encoder(report) -> None:
+    """BASELINE config 3 in miniature: wise(0.5 teacher + 0.5 student) on the tiny dims, oracle outputs."""
+    d = synth.TINY
+    sd1_np = synth.make_state_dict(d, seed=42)
+    sd2_np = synth.perturbed_state_dict(sd1_np, d, seed=43, rel=0.2)
+    sd = O.wise_state_dict(O.to_torch(sd1_np), O.to_torch(sd2_np), 0.5)
+    video = torch.from_numpy(synth.make_video(6, 2, d, seed=42))
+    ids = torch.from_numpy(synth.make_text(6, d, seed=42))
+    with torch.inference_mode():
+        ev, et = O.forward(sd, video, {"input_ids": ids})
+    np.savez(HERE / "wise_encoder_tiny.npz", seed=42, student_seed=43, rel=0.2, weight_for_2=0.5,
+             encoded_videos=ev.numpy(), encoded_texts=et.numpy())
+    report["wise_encoder_tiny"] = "oracle outputs stored"
+
+
+def main() -> None:
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    report = {"generated_by": "tests/golden/make_goldens.py", "torch": torch.__version__}
+    ref_wise, ref_loss, ref_slip = _import_reference()
+    golden_wise(ref_wise, report)
+    golden_loss(ref_loss, report)
+    golden_towers(ref_slip, report)
+    golden_evaluate(report)
+    golden_wise_encoder(report)
+    (HERE / "PINNING.json").write_text(json.dumps(report, indent=2) + "\n")
+    print(json.dumps(report, indent=2))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""CPU: the oracle reproduces every golden fixture (which were themselves checked against the reference's own
+`aligner.wise`, `aligner.loss`, `aligner.encoder.slip` classes and HF CLIP by tests/golden/make_goldens.py)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from fitclip_amd import synth
+from oracle import clip_oracle as O
+
+TOL = 2e-5
+
+
+def test_pinning_report_is_tight(golden_dir):
+    rep = json.loads((golden_dir / "PINNING.json").read_text())
+    assert rep["loss_vs_reference_aligner.loss_maxabs"] < 1e-5
+    for tag in ("tiny", "vitb16"):
+        d = rep[f"towers_{tag}_maxabs"]
+        for k, v in d.items():
+            if k != "output_abs_max":
+                assert v < TOL * max(1.0, d["output_abs_max"]), (tag, k, v)
+
+
+def test_wise_matches_reference_fixture(golden_dir):
+    g = np.load(golden_dir / "wise_ref.npz")
+    names = sorted(k[3:] for k in g.files if k.startswith("m1_"))
+    sd1 = {n: torch.from_numpy(g[f"m1_{n}"]) for n in names}
+    sd2 = {n: torch.from_numpy(g[f"m2_{n}"]) for n in names}
+    for w in (0.0, 0.4, 0.5, 1.0):
+        out = O.wise_state_dict(sd1, sd2, w)
+        for n in names:
+            assert np.array_equal(out[n].numpy(), g[f"w{w}_{n}"]), (w, n)
+
+
+def test_wise_rejects_key_mismatch():
+    with pytest.raises(AssertionError):
+        O.wise_state_dict({"a": torch.zeros(1)}, {"b": torch.zeros(1)}, 0.5)
+
+
+def test_losses_match_reference_fixture(golden_dir):
+    g = np.load(golden_dir / "loss_ref.npz")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files})
+    assert tags
+    for t in tags:
+        s, te = torch.from_numpy(g[f"{t}_scores"]), torch.from_numpy(g[f"{t}_teacher"])
+        assert abs(float(O.nce_loss(s)) - float(g[f"{t}_nce"])) < 1e-5
+        assert abs(float(O.teacher_student_nce_loss(s, te)) - float(g[f"{t}_kd"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag,dims", [("tiny", synth.TINY), ("vitb16", synth.VIT_B_16)])
+def test_towers_match_reference_slip_and_hf(golden_dir, tag, dims, request):
+    g = np.load(golden_dir / f"towers_{tag}.npz")
+    sd = O.to_torch(request.getfixturevalue(f"{tag}_state_dict"))
+    video = torch.from_numpy(synth.make_video(int(g["n_clip"]), int(g["n_frames"]), dims, seed=int(g["seed"])))
+    ids = torch.from_numpy(synth.make_text(int(g["n_text"]), dims, seed=int(g["seed"])))
+    assert np.array_equal(ids.numpy(), g["ids"])
+    with torch.inference_mode():
+        img = O.encode_image(sd, video.reshape(-1, *video.shape[2:])).numpy()
+        txt = O.encode_text_tokens(sd, ids).numpy()
+        txt_rand = O.encode_text_tokens(sd, torch.from_numpy(g["ids_rand"])).numpy()
+    for ref in ("slip", "hf"):
+        assert np.abs(img - g[f"image_features_{ref}"]).max() < TOL * 4
+        assert np.abs(txt - g[f"text_features_{ref}"]).max() < TOL * 4
+    assert np.abs(txt_rand - g["text_features_rand_slip"]).max() < TOL * 4
+
+
+def test_evaluate_tiny_golden(golden_dir, tiny_state_dict):
+    g = np.load(golden_dir / "evaluate_tiny.npz")
+    d = synth.TINY
+    sd = O.to_torch(tiny_state_dict)
+    n, f = int(g["n_clips"]), int(g["n_frames"])
+    video = torch.from_numpy(synth.make_video(n, f, d, seed=42))
+    ids = torch.from_numpy(synth.make_text(n, d, seed=42))
+    with torch.inference_mode():
+        ev, et = O.forward(sd, video, {"input_ids": ids})
+    assert np.abs(ev.numpy() - g["encoded_videos"]).max() < TOL
+    assert np.abs(et.numpy() - g["encoded_texts"]).max() < TOL
+    scores = O.retrieval_scores(et, ev)
+    m = O.retrieval_metrics(scores)
+    for k in ("r1", "r5", "r10", "mr"):
+        assert m[k] == pytest.approx(float(g[k]))
+    assert abs(float(O.nce_loss(O.step_scores(ev, et, 0.015))) - float(g["loss_val"])) < 1e-3
+
+
+def test_rank_known_answers_with_ties():
+    # hand-built: row i's target is column i
+    s = torch.tensor([[9., 1., 2., 3., 4.],     # target is the max           -> rank 0
+                      [5., 5., 5., 5., 5.],     # all tied: one tie before it -> rank 1 (stable order)
+                      [1., 2., 0., 4., 3.],     # 4 larger                    -> rank 4
+                      [7., 3., 7., 7., 1.],     # two larger-or-tied-before   -> rank 2
+                      [0., 0., 0., 0., 1.]])    # max                         -> rank 0
+    r = O.ranks_of_target(s, torch.arange(5))
+    assert r.tolist() == [0, 1, 4, 2, 0]
+    m = O.retrieval_metrics(s)
+    assert m["r1"] == pytest.approx(0.4) and m["r5"] == pytest.approx(1.0) and m["mr"] == 2.0
+
+
+def test_median_rank_is_lower_middle_plus_one():
+    s = torch.eye(4)
+    s[2] = torch.tensor([0.9, 0.8, 0.1, 0.7])  # rank 3
+    s[3] = torch.tensor([0.9, 0.8, 0.7, 0.75])  # rank 3
+    m = O.retrieval_metrics(s)
+    # ranks = [0, 0, 3, 3] -> torch.median lower middle = 0 -> +1
+    assert m["mr"] == 1.0
+
+
+def test_flatten_gathered_layout():
+    t = torch.arange(2 * 3 * 4).view(2, 3, 4)
+    assert torch.equal(O.flatten_gathered(t), t.view(6, 4))
+
+
+def test_synth_is_deterministic_and_sliceable():
+    a = synth.make_video(3, 2, synth.TINY, seed=5)
+    b = synth.make_video(1, 2, synth.TINY, seed=5, first_clip=2)
+    assert np.array_equal(a[2], b[0])
+    t = synth.make_text(5, synth.TINY, seed=5)
+    assert np.array_equal(t[3:], synth.make_text(2, synth.TINY, seed=5, first_text=3))
+    eot = synth.TINY.vocab_size - 1
+    assert (t.max(axis=1) == eot).all() and (t[:, 0] == eot - 1).all()
+    assert len(synth.parameter_shapes(synth.VIT_B_16)) == 301
+    assert sum(int(np.prod(s)) for s in synth.parameter_shapes(synth.VIT_B_16).values()) == 149_620_736
