@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: video-text pairs/s of the FitCLIP encode-and-score path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic input, inputs already resident in HBM:
+  encode_video(256 clips x 8 frames x 3 x 224 x 224 fp32)  +  encode_text(256 x 77 ids)   (CLIP ViT-B/16, random init)
+  -> [all-gather of the embeddings over RCCL when N > 1] -> T @ V^T -> rank of every caption's clip.
+Per-GPU work is fixed as N grows (each rank encodes its own 256 clips): "scaling": "weak"; `value` is whole-job
+pairs/s = N * 256 / (max over ranks of the step time).
+
+The same JSON line carries
+  * "roofline": the dominant kernel (the MFMA GEMM instantiation with the largest total time), its average launch
+    duration measured with hipEvent pairs recorded by the library around every GEMM launch on the stream the kernels
+    run on, inside the timed region; achieved = algorithmic FLOPs per launch / that duration; peak = dense MFMA peak of
+    the dtype (2.5 PFLOP/s bf16, 157.3 TFLOP/s fp32-input MFMA; MI355X_MICROARCH.md).
+  * "cpu_baseline": the CPU oracle (oracle/clip_oracle.py, kind "port") timed on this host's cores over a bounded
+    sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+GF_PER_FRAME = 35.127e9   # BASELINE.md section 3 (GEMM + attention MACs x 2)
+GF_PER_TEXT = 5.960e9
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+EPI_NAMES = {0: "bias", 1: "bias_quickgelu", 2: "bias_residual", 3: "patch_embed", 4: "store_f32"}
+
+
+def synth_video_on_device(n_clips: int, n_frames: int, res: int, seed: int, device) -> torch.Tensor:
+    """Clip-specific low-frequency pattern + per-frame noise, clipped to the CLIP-normalised pixel range (the same
+    recipe as fitclip_amd.synth.make_video, generated with the device RNG so 1.2 GB never cross PCIe)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    low = torch.randn((n_clips, 1, 3, 8, 8), generator=g, device=device)
+    base = torch.nn.functional.interpolate(low.view(n_clips, 3, 8, 8), size=(res, res), mode="nearest")
+    video = torch.randn((n_clips, n_frames, 3, res, res), generator=g, device=device).mul_(0.5)
+    video.add_(base.unsqueeze(1)).clamp_(-2.5, 2.5)
+    return video
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--clips", type=int, default=256, help="clips (= captions) per GPU per step")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--chunk-frames", type=int, default=0)
+    ap.add_argument("--gemm-tile", type=int, default=0)
+    ap.add_argument("--cpu-sample-clips", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from fitclip_amd import distributed as D
+    from fitclip_amd import ops, synth
+    from fitclip_amd.clip_model import build_clip
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+
+    dims = synth.VIT_B_16
+    sd = synth.make_state_dict(dims, seed=42)
+    enc = ClipVideoTextEncoder(build_clip(sd, precision=args.precision, device=device,
+                                          chunk_frames=args.chunk_frames, gemm_tile=args.gemm_tile),
+                               num_frames=args.frames)
+    n_local, n_total = args.clips, args.clips * world
+    video = synth_video_on_device(n_local, args.frames, dims.image_resolution, seed=1000 + rank, device=device)
+    ids = torch.from_numpy(synth.make_text(n_local, dims, seed=42, first_text=rank * n_local)).to(device)
+    text = {"input_ids": ids}
+    counts = [n_local] * world
+
+    def step():
+        ev, et = enc(video=video, text=text)
+        all_v = D.all_gather_rows(ev, counts)
+        scores = ops.similarity(et, all_v)
+        ranks = ops.ranks(scores, rank * n_local)
+        return ev, et, D.all_gather_rows(ranks, counts)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    enc.model.profile(16384)
+    enc.model.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev, et, all_ranks = step()
+    fence()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    records = enc.model.profile_records()
+    enc.model.profile(0)
+
+    # ---- dominant kernel (by total time) from the in-run hipEvent pairs
+    by_kernel = defaultdict(lambda: [0.0, 0, 0.0])
+    for r in records:
+        if r["ms"] <= 0:
+            continue
+        key = (r["epilogue"], r["N"], r["K"], r["M"])
+        agg = by_kernel[key]
+        agg[0] += r["ms"]
+        agg[1] += 1
+        agg[2] += 2.0 * r["M"] * r["N"] * r["K"]
+    gemm_ms = sum(v[0] for v in by_kernel.values())
+    gemm_flops = sum(v[2] for v in by_kernel.values())
+    (epi, N, K, M), (ms, cnt, flops) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+    peak = PEAK_TFLOPS[args.precision]
+    achieved = flops / (ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision},{EPI_NAMES[epi]}> M={M} N={N} K={K}",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                "flops_per_launch": flops / cnt,
+                "share_of_step_time": round(ms / (elapsed * 1e3), 4)}
+    step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
+    all_gemms = {"achieved": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                 "frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                 "share_of_step_time": round(gemm_ms / (elapsed * 1e3), 4)}
+    whole_path = {"achieved": round(step_flops * args.steps / elapsed / 1e12, 2), "unit": "TFLOP/s",
+                  "frac": round(step_flops * args.steps / elapsed / 1e12 / peak, 4)}
+
+    metrics = D.metrics_from_ranks(all_ranks.cpu().numpy())
+    result = {
+        "metric": "video-text pairs/sec (8-frame 224^2, 77-tok)", "value": round(n_total * args.steps / elapsed, 2),
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"CLIP ViT-B/16 dual encoder, {n_local} clips x {args.frames} frames x 224^2 + {n_local} "
+                               f"x 77-token texts per GPU -> T@V^T -> ranks (BASELINE configs[1])",
+                   "clips_per_gpu": n_local, "frames": args.frames, "weights": "random init (seed 42)",
+                   "sharding": f"clips over {world} rank(s), one RCCL all-gather of embeddings"},
+        "roofline": roofline, "roofline_all_gemms": all_gemms, "roofline_whole_path": whole_path,
+        "retrieval": metrics,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import clip_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd_t = O.to_torch(sd)
+        k = min(args.cpu_sample_clips, n_local)
+        v_cpu, ids_cpu = video[:k].cpu(), ids[:k].cpu()
+        with torch.inference_mode():
+            O.encode_image(sd_t, v_cpu[0, :1])  # warm the thread pool
+            t0 = time.perf_counter()
+            ev_ref, et_ref = O.forward(sd_t, v_cpu, {"input_ids": ids_cpu})
+            cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(k / cpu_s, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+                                  "sample": f"{k} clips x {args.frames} frames + {k} texts of the same batch, "
+                                            f"fp32 PyTorch oracle, {cores} threads, {cpu_s:.1f} s"}
+        dv, dt = (ev[:k].cpu() - ev_ref).abs().max().item(), (et[:k].cpu() - et_ref).abs().max().item()
+        sig = float((ev_ref - ev_ref.mean(0, keepdim=True)).norm(dim=1).mean())
+        result["parity_vs_oracle_on_sample"] = {"video_max_abs": dv, "text_max_abs": dt,
+                                                "video_signal_norm": sig}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

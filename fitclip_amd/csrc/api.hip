@@ -1,0 +1,501 @@
+// C ABI of libfitclip_hip.so (see include/fitclip_hip.h): handle, weight table, and the two tower forwards that
+// sequence the HIP kernels of this directory on the caller's stream.  No device allocation, no synchronisation.
+#include "../../include/fitclip_hip.h"
+#include "common.h"
+
+#include <cstdarg>
+#include <map>
+#include <memory>
+#include <vector>
+
+namespace fc {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string& msg) { g_error = msg; }
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+namespace {
+
+struct WeightSlot {
+  std::vector<int64_t> shape;
+  const float* ptr = nullptr;
+};
+
+struct Block {
+  const float *ln1_w, *ln1_b, *in_b, *out_b, *ln2_w, *ln2_b, *fc_b, *proj_b;
+  const void *in_w, *out_w, *fc_w, *proj_w;  // element type T of the handle's precision, [N, K]
+};
+
+struct Tower {
+  std::vector<Block> blocks;
+};
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+}  // namespace fc
+
+struct fc_handle {
+  fc_config cfg{};
+  int esz = 4;  // bytes per activation / GEMM-weight element
+  std::vector<std::string> names;
+  std::map<std::string, fc::WeightSlot> slots;
+  bool packed = false;
+  fc::Tower vis, txt;
+  const void *conv_w = nullptr, *vproj_t = nullptr, *tproj_t = nullptr;
+  // profiling
+  std::vector<hipEvent_t> ev;
+  std::vector<fc_prof_record> recs;
+  int prof_cap = 0;
+
+  int vheads() const { return cfg.vision_width / 64; }
+  int grid() const { return cfg.image_resolution / cfg.vision_patch_size; }
+  int patches() const { return grid() * grid(); }
+  int vtokens() const { return patches() + 1; }
+  int patch_k() const { return 3 * cfg.vision_patch_size * cfg.vision_patch_size; }
+  const float* w(const std::string& n) const { return slots.at(n).ptr; }
+};
+
+namespace fc {
+namespace {
+
+void add_blocks(fc_handle* h, const std::string& prefix, int width, int layers) {
+  auto add = [&](const std::string& n, std::vector<int64_t> shape) {
+    h->names.push_back(n);
+    h->slots[n].shape = std::move(shape);
+  };
+  for (int i = 0; i < layers; ++i) {
+    const std::string b = prefix + ".resblocks." + std::to_string(i);
+    add(b + ".attn.in_proj_weight", {3L * width, width});
+    add(b + ".attn.in_proj_bias", {3L * width});
+    add(b + ".attn.out_proj.weight", {width, width});
+    add(b + ".attn.out_proj.bias", {width});
+    add(b + ".ln_1.weight", {width});
+    add(b + ".ln_1.bias", {width});
+    add(b + ".mlp.c_fc.weight", {4L * width, width});
+    add(b + ".mlp.c_fc.bias", {4L * width});
+    add(b + ".mlp.c_proj.weight", {width, 4L * width});
+    add(b + ".mlp.c_proj.bias", {width});
+    add(b + ".ln_2.weight", {width});
+    add(b + ".ln_2.bias", {width});
+  }
+}
+
+void build_names(fc_handle* h) {
+  const fc_config& c = h->cfg;
+  auto add = [&](const std::string& n, std::vector<int64_t> shape) {
+    h->names.push_back(n);
+    h->slots[n].shape = std::move(shape);
+  };
+  const int64_t vw = c.vision_width, tw = c.transformer_width, p = c.vision_patch_size;
+  add("positional_embedding", {c.context_length, tw});
+  add("text_projection", {tw, c.embed_dim});
+  add("visual.class_embedding", {vw});
+  add("visual.positional_embedding", {h->vtokens(), vw});
+  add("visual.proj", {vw, c.embed_dim});
+  add("visual.conv1.weight", {vw, 3, p, p});
+  add("visual.ln_pre.weight", {vw});
+  add("visual.ln_pre.bias", {vw});
+  add_blocks(h, "visual.transformer", (int)vw, c.vision_layers);
+  add("visual.ln_post.weight", {vw});
+  add("visual.ln_post.bias", {vw});
+  add_blocks(h, "transformer", (int)tw, c.transformer_layers);
+  add("token_embedding.weight", {c.vocab_size, tw});
+  add("ln_final.weight", {tw});
+  add("ln_final.bias", {tw});
+}
+
+size_t numel(const std::vector<int64_t>& s) {
+  size_t n = 1;
+  for (auto v : s) n *= (size_t)v;
+  return n;
+}
+
+// GEMM weights that get a kernel-layout copy: (name, transpose?)
+std::vector<std::pair<std::string, bool>> packed_list(const fc_handle* h) {
+  std::vector<std::pair<std::string, bool>> l;
+  const bool conv = h->cfg.precision == FC_PREC_BF16;  // f32 mode uses the caller's tensors directly
+  auto blocks = [&](const std::string& prefix, int layers) {
+    for (int i = 0; i < layers; ++i) {
+      const std::string b = prefix + ".resblocks." + std::to_string(i);
+      l.push_back({b + ".attn.in_proj_weight", false});
+      l.push_back({b + ".attn.out_proj.weight", false});
+      l.push_back({b + ".mlp.c_fc.weight", false});
+      l.push_back({b + ".mlp.c_proj.weight", false});
+    }
+  };
+  if (conv) {
+    l.push_back({"visual.conv1.weight", false});
+    blocks("visual.transformer", h->cfg.vision_layers);
+    blocks("transformer", h->cfg.transformer_layers);
+  }
+  l.push_back({"visual.proj", true});
+  l.push_back({"text_projection", true});
+  return l;
+}
+
+struct ProfScope {
+  fc_handle* h;
+  hipStream_t st;
+  int idx = -1;
+  ProfScope(fc_handle* h_, hipStream_t st_, int prec, int epi, int tile, const GemmArgs& a) : h(h_), st(st_) {
+    if (h && h->prof_cap && (int)h->recs.size() < h->prof_cap) {
+      idx = (int)h->recs.size();
+      fc_prof_record r{};
+      r.kind = 0; r.precision = prec; r.epilogue = epi; r.tile = tile; r.M = a.M; r.N = a.N; r.K = a.K; r.ms = -1.f;
+      h->recs.push_back(r);
+      (void)hipEventRecord(h->ev[2 * idx], st);
+    }
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(h->ev[2 * idx + 1], st);
+  }
+};
+
+int gemm(fc_handle* h, int epi, const void* A, const void* W, const float* bias, void* C, const float* aux, int M,
+         int N, int K, int ldc, int P, hipStream_t st) {
+  GemmArgs a{};
+  a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = aux; a.alpha = 1.f;
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = ldc; a.P = P;
+  ProfScope ps(h, st, h->cfg.precision, epi, h->cfg.gemm_tile, a);
+  return launch_gemm(h->cfg.precision, epi, a, h->cfg.gemm_tile, st);
+}
+
+#define FC_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != FC_OK) return _rc; \
+  } while (0)
+
+struct Scratch {
+  float* x;
+  char* xn;
+  char* big;
+  char* clsn;
+  int* eot;
+  size_t total;
+};
+
+// workspace carve for `c` items of `tokens` tokens and width `w` (base may be null: sizes only)
+Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols) {
+  Scratch s{};
+  const size_t M = (size_t)c * tokens;
+  const size_t big_cols = (size_t)std::max(4 * w, min_big_cols);
+  const size_t o_x = 0;
+  const size_t o_xn = o_x + align_up(M * w * 4);
+  const size_t o_big = o_xn + align_up(M * w * esz);
+  const size_t o_cls = o_big + align_up(M * big_cols * esz);
+  const size_t o_eot = o_cls + align_up((size_t)c * w * esz);
+  s.total = o_eot + align_up((size_t)c * 4);
+  if (base) {
+    s.x = reinterpret_cast<float*>(base + o_x);
+    s.xn = base + o_xn;
+    s.big = base + o_big;
+    s.clsn = base + o_cls;
+    s.eot = reinterpret_cast<int*>(base + o_eot);
+  }
+  return s;
+}
+
+int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal,
+               hipStream_t st) {
+  const int M = n_seq * S;
+  const int kind = h->cfg.precision;
+  for (const Block& b : t.blocks) {
+    FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
+    FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, 0, st));
+    FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
+    FC_TRY(gemm(h, EPI_RESID_F32, s.xn, b.out_w, b.out_b, s.x, nullptr, M, w, w, w, 0, st));
+    FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, st));
+    FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
+    FC_TRY(gemm(h, EPI_RESID_F32, s.big, b.proj_w, b.proj_b, s.x, nullptr, M, w, 4 * w, w, 0, st));
+  }
+  return FC_OK;
+}
+
+int default_chunk(const fc_handle* h, int tower) {
+  if (tower == 0) return h->cfg.chunk_frames > 0 ? h->cfg.chunk_frames : 256;
+  return h->cfg.chunk_texts > 0 ? h->cfg.chunk_texts : 1024;
+}
+
+size_t per_item_bytes(const fc_handle* h, int tower) {
+  const fc_config& c = h->cfg;
+  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_k()).total;
+  return carve(nullptr, 1, c.context_length, c.transformer_width, h->esz, 0).total;
+}
+
+}  // namespace
+}  // namespace fc
+
+using namespace fc;
+
+extern "C" {
+
+const char* fc_last_error(void) { return g_error.c_str(); }
+const char* fc_version(void) { return "fitclip_hip 0.1 (gfx950)"; }
+
+int fc_create(const fc_config* cfg, fc_handle** out) {
+  if (!cfg || !out) return fail(FC_EINVAL, "fc_create: null argument");
+  const fc_config& c = *cfg;
+  if (c.precision != FC_PREC_F32 && c.precision != FC_PREC_BF16) return fail(FC_EINVAL, "fc_create: precision");
+  if (c.vision_width % 64 || c.transformer_width % 64 || c.vision_width <= 0 || c.transformer_width <= 0)
+    return fail(FC_EINVAL, "fc_create: widths must be positive multiples of 64 (head dim 64)");
+  if (c.transformer_heads * 64 != c.transformer_width)
+    return fail(FC_EINVAL, "fc_create: transformer_heads * 64 must equal transformer_width");
+  if (c.vision_patch_size <= 0 || c.image_resolution % c.vision_patch_size || c.vision_patch_size % 4)
+    return fail(FC_EINVAL, "fc_create: resolution %d / patch %d", c.image_resolution, c.vision_patch_size);
+  if (c.embed_dim % 4 || c.embed_dim <= 0 || c.vision_layers <= 0 || c.transformer_layers <= 0 ||
+      c.context_length <= 0 || c.vocab_size <= 0)
+    return fail(FC_EINVAL, "fc_create: bad dimension");
+  const int kmult = c.precision == FC_PREC_BF16 ? 64 : 32;
+  if ((3 * c.vision_patch_size * c.vision_patch_size) % kmult)
+    return fail(FC_EINVAL, "fc_create: 3*patch^2 must be a multiple of %d", kmult);
+  auto h = std::make_unique<fc_handle>();
+  h->cfg = c;
+  h->esz = c.precision == FC_PREC_BF16 ? 2 : 4;
+  build_names(h.get());
+  const int vt = h->vtokens();
+  if ((c.precision == FC_PREC_BF16 && (vt > 224 || c.context_length > 224)))
+    return fail(FC_EINVAL, "fc_create: sequences longer than 224 tokens are not supported in bf16 mode");
+  *out = h.release();
+  return FC_OK;
+}
+
+void fc_destroy(fc_handle* h) {
+  if (!h) return;
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int fc_num_weights(const fc_handle* h) { return h ? (int)h->names.size() : 0; }
+const char* fc_weight_name(const fc_handle* h, int32_t i) {
+  return (h && i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : nullptr;
+}
+
+int fc_set_weight(fc_handle* h, const char* name, const float* dev, const int64_t* shape, int32_t ndim) {
+  if (!h || !name) return fail(FC_EINVAL, "fc_set_weight: null argument");
+  const std::string n(name);
+  if (n == "logit_scale" || n == "input_resolution" || n == "context_length" || n == "vocab_size") return FC_OK;
+  auto it = h->slots.find(n);
+  if (it == h->slots.end()) return fail(FC_EINVAL, "fc_set_weight: unexpected key \"%s\"", name);
+  const auto& want = it->second.shape;
+  bool ok = (int)want.size() == ndim;
+  for (int i = 0; ok && i < ndim; ++i) ok = want[i] == shape[i];
+  if (!ok) return fail(FC_EINVAL, "fc_set_weight: shape mismatch for \"%s\"", name);
+  if (!dev || ((uintptr_t)dev & 15)) return fail(FC_EINVAL, "fc_set_weight: \"%s\" must be a 16-byte aligned device pointer", name);
+  it->second.ptr = dev;
+  h->packed = false;
+  return FC_OK;
+}
+
+size_t fc_packed_bytes(const fc_handle* h) {
+  if (!h) return 0;
+  size_t total = 0;
+  for (auto& e : packed_list(h)) total += align_up(numel(h->slots.at(e.first).shape) * h->esz);
+  return total;
+}
+
+int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
+  if (!h) return fail(FC_EINVAL, "fc_pack_weights: null handle");
+  for (auto& n : h->names)
+    if (!h->slots[n].ptr) return fail(FC_ESTATE, "fc_pack_weights: missing key \"%s\"", n.c_str());
+  if (bytes < fc_packed_bytes(h) || !arena || ((uintptr_t)arena & 255))
+    return fail(FC_ENOMEM, "fc_pack_weights: arena needs %zu bytes, 256-byte aligned", fc_packed_bytes(h));
+  const int kind = h->cfg.precision;
+  std::map<std::string, const void*> packed;
+  size_t off = 0;
+  for (auto& e : packed_list(h)) {
+    const auto& slot = h->slots.at(e.first);
+    void* dst = static_cast<char*>(arena) + off;
+    if (e.second) {
+      FC_TRY(launch_transpose_convert(slot.ptr, dst, kind, (int)slot.shape[0], (int)slot.shape[1], stream));
+    } else {
+      FC_TRY(launch_convert(slot.ptr, dst, kind, numel(slot.shape), stream));
+    }
+    packed[e.first] = dst;
+    off += align_up(numel(slot.shape) * h->esz);
+  }
+  auto gw = [&](const std::string& n) -> const void* {
+    auto it = packed.find(n);
+    return it != packed.end() ? it->second : static_cast<const void*>(h->w(n));
+  };
+  auto fill = [&](Tower& t, const std::string& prefix, int layers) {
+    t.blocks.assign(layers, Block{});
+    for (int i = 0; i < layers; ++i) {
+      const std::string b = prefix + ".resblocks." + std::to_string(i);
+      Block& k = t.blocks[i];
+      k.ln1_w = h->w(b + ".ln_1.weight"); k.ln1_b = h->w(b + ".ln_1.bias");
+      k.ln2_w = h->w(b + ".ln_2.weight"); k.ln2_b = h->w(b + ".ln_2.bias");
+      k.in_b = h->w(b + ".attn.in_proj_bias"); k.out_b = h->w(b + ".attn.out_proj.bias");
+      k.fc_b = h->w(b + ".mlp.c_fc.bias"); k.proj_b = h->w(b + ".mlp.c_proj.bias");
+      k.in_w = gw(b + ".attn.in_proj_weight"); k.out_w = gw(b + ".attn.out_proj.weight");
+      k.fc_w = gw(b + ".mlp.c_fc.weight"); k.proj_w = gw(b + ".mlp.c_proj.weight");
+    }
+  };
+  fill(h->vis, "visual.transformer", h->cfg.vision_layers);
+  fill(h->txt, "transformer", h->cfg.transformer_layers);
+  h->conv_w = gw("visual.conv1.weight");
+  h->vproj_t = gw("visual.proj");
+  h->tproj_t = gw("text_projection");
+  h->packed = true;
+  return FC_OK;
+}
+
+size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n) {
+  if (!h || n <= 0 || tower < 0 || tower > 1) return 0;
+  const int c = std::min(n, default_chunk(h, tower));
+  const fc_config& k = h->cfg;
+  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_k()).total
+                    : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0).total;
+}
+
+int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, void* ws, size_t ws_bytes,
+                    fc_stream st) {
+  if (!h) return fail(FC_EINVAL, "fc_encode_image: null handle");
+  if (!h->packed) return fail(FC_ESTATE, "fc_encode_image: call fc_pack_weights first");
+  if (n == 0) return FC_OK;
+  if (n < 0 || !frames || !out || !ws) return fail(FC_EINVAL, "fc_encode_image: bad argument");
+  if (((uintptr_t)frames | (uintptr_t)out | (uintptr_t)ws) & 15) return fail(FC_EINVAL, "fc_encode_image: unaligned pointer");
+  const fc_config& c = h->cfg;
+  const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_k();
+  const size_t per = per_item_bytes(h, 0);
+  int chunk = std::min<long>(std::min(n, default_chunk(h, 0)), (long)(ws_bytes / per));
+  // the carve aligns every buffer to 256 B; shrink until the exact layout fits
+  while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) --chunk;
+  if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_image: workspace too small (need >= %zu bytes)", per + 2048);
+  const int kind = c.precision;
+  for (int off = 0; off < n; off += chunk) {
+    const int cn = std::min(chunk, n - off);
+    const Scratch s = carve(static_cast<char*>(ws), cn, T, vw, h->esz, Kp);
+    const float* f = frames + (size_t)off * 3 * R * R;
+    FC_TRY(launch_im2col(f, s.big, kind, cn, R, c.vision_patch_size, st));
+    FC_TRY(gemm(h, EPI_PATCH_F32, s.big, h->conv_w, nullptr, s.x, h->w("visual.positional_embedding"), cn * P, vw, Kp,
+                vw, P, st));
+    FC_TRY(launch_cls_pos(s.x, h->w("visual.class_embedding"), h->w("visual.positional_embedding"), cn, T, vw, st));
+    FC_TRY(launch_layernorm(s.x, vw, nullptr, h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias"), s.x, vw, 0,
+                            cn * T, vw, st));
+    FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, st));
+    FC_TRY(launch_layernorm(s.x, (long)T * vw, nullptr, h->w("visual.ln_post.weight"), h->w("visual.ln_post.bias"),
+                            s.clsn, vw, kind, cn, vw, st));
+    FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
+                c.embed_dim, vw, c.embed_dim, 0, st));
+  }
+  return FC_OK;
+}
+
+int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void* ws, size_t ws_bytes, fc_stream st) {
+  if (!h) return fail(FC_EINVAL, "fc_encode_text: null handle");
+  if (!h->packed) return fail(FC_ESTATE, "fc_encode_text: call fc_pack_weights first");
+  if (n == 0) return FC_OK;
+  if (n < 0 || !ids || !out || !ws) return fail(FC_EINVAL, "fc_encode_text: bad argument");
+  if (((uintptr_t)out | (uintptr_t)ws) & 15) return fail(FC_EINVAL, "fc_encode_text: unaligned pointer");
+  const fc_config& c = h->cfg;
+  const int tw = c.transformer_width, L = c.context_length;
+  const size_t per = per_item_bytes(h, 1);
+  int chunk = std::min<long>(std::min(n, default_chunk(h, 1)), (long)(ws_bytes / per));
+  while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) --chunk;
+  if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_text: workspace too small (need >= %zu bytes)", per + 2048);
+  const int kind = c.precision;
+  for (int off = 0; off < n; off += chunk) {
+    const int cn = std::min(chunk, n - off);
+    const Scratch s = carve(static_cast<char*>(ws), cn, L, tw, h->esz, 0);
+    FC_TRY(launch_text_embed(ids + (size_t)off * L, h->w("token_embedding.weight"), h->w("positional_embedding"), s.x,
+                             s.eot, cn, L, tw, c.vocab_size, st));
+    FC_TRY(run_blocks(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, st));
+    FC_TRY(launch_layernorm(s.x, tw, s.eot, h->w("ln_final.weight"), h->w("ln_final.bias"), s.clsn, tw, kind, cn, tw,
+                            st));
+    FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->tproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
+                c.embed_dim, tw, c.embed_dim, 0, st));
+  }
+  return FC_OK;
+}
+
+int fc_pool_normalize(const float* e, float* out, int32_t n_clips, int32_t frames, int32_t dim, fc_stream st) {
+  return launch_pool_normalize(e, out, n_clips, frames, dim, st);
+}
+int fc_l2_normalize(const float* in, float* out, int32_t n, int32_t dim, fc_stream st) {
+  return launch_l2_normalize(in, out, n, dim, st);
+}
+
+int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb, int32_t dim, float alpha, float* out,
+                  int32_t ldo, fc_stream st) {
+  if (na == 0 || nb == 0) return FC_OK;
+  GemmArgs a{};
+  a.A = A; a.W = B; a.bias = nullptr; a.C = out; a.aux = nullptr; a.alpha = alpha;
+  a.M = na; a.N = nb; a.K = dim; a.lda = dim; a.ldw = dim; a.ldc = ldo; a.P = 0;
+  return launch_gemm(PREC_F32, EPI_STORE_F32, a, 1, st);
+}
+int fc_ranks(const float* s, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t off, int32_t* ranks, fc_stream st) {
+  return launch_ranks(s, ld, n_rows, n_cols, off, ranks, st);
+}
+int fc_nce_loss(const float* s, int32_t n, float* out, float* ws, fc_stream st) { return launch_nce_loss(s, n, out, ws, st); }
+int fc_kd_loss(const float* s, const float* t, int32_t n, float* out, float* ws, fc_stream st) {
+  return launch_kd_loss(s, t, n, out, ws, st);
+}
+int fc_wise(const float* a, const float* b, double w, float* out, size_t n, fc_stream st) {
+  return launch_wise(a, b, w, out, n, st);
+}
+
+int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const void* W, const float* bias, void* C,
+            const float* aux, float alpha, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
+            int32_t P, int32_t tile, fc_stream st) {
+  GemmArgs a{};
+  a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = aux; a.alpha = alpha;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.P = P;
+  return launch_gemm(precision, epilogue, a, tile, st);
+}
+int fc_layernorm(const float* x, int64_t xs, const int32_t* gather, const float* g, const float* b, void* y,
+                 int64_t ys, int32_t out_kind, int32_t rows, int32_t D, fc_stream st) {
+  return launch_layernorm(x, (long)xs, gather, g, b, y, (long)ys, out_kind, rows, D, st);
+}
+int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
+                 int32_t causal, fc_stream st) {
+  return launch_attention(precision, qkv, out, n_seq, S, heads, causal, st);
+}
+int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream st) {
+  return launch_convert(in, out, out_kind, n, st);
+}
+
+int fc_profile_enable(fc_handle* h, int32_t max_records) {
+  if (!h || max_records < 0) return fail(FC_EINVAL, "fc_profile_enable: bad argument");
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  h->ev.clear();
+  h->recs.clear();
+  h->prof_cap = 0;
+  for (int i = 0; i < 2 * max_records; ++i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return fail(FC_ELAUNCH, "fc_profile_enable: hipEventCreate failed");
+    h->ev.push_back(e);
+  }
+  h->recs.reserve(max_records);
+  h->prof_cap = max_records;
+  return FC_OK;
+}
+int fc_profile_reset(fc_handle* h) {
+  if (!h) return fail(FC_EINVAL, "fc_profile_reset: null handle");
+  h->recs.clear();
+  return FC_OK;
+}
+int fc_profile_read(fc_handle* h, fc_prof_record* out, int32_t max_records) {
+  if (!h || !out) return fail(FC_EINVAL, "fc_profile_read: null argument");
+  const int n = std::min<int>((int)h->recs.size(), max_records);
+  for (int i = 0; i < n; ++i) {
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) != hipSuccess) ms = -1.f;
+    h->recs[i].ms = ms;
+    out[i] = h->recs[i];
+  }
+  return n;
+}
+
+}  // extern "C"

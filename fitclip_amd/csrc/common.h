@@ -1,0 +1,95 @@
+// Shared declarations for the fitclip HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/fitclip_hip.h"
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace fc {
+
+using bf16 = __bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
+
+// error codes: fc_status of the public header
+
+void set_error(const std::string& msg);
+int fail(int code, const char* fmt, ...);
+
+#define FC_CHECK_LAUNCH(what)                                                          \
+  do {                                                                                 \
+    hipError_t _e = hipGetLastError();                                                 \
+    if (_e != hipSuccess) return ::fc::fail(FC_ELAUNCH, "%s: %s", what, hipGetErrorString(_e)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T).  A and W are both K-contiguous (W is a torch Linear weight as stored).
+enum Epilogue : int {
+  EPI_BIAS_T = 0,     // C(T)   = acc + bias
+  EPI_GELU_T = 1,     // C(T)   = quickgelu(acc + bias)
+  EPI_RESID_F32 = 2,  // C(f32) += acc + bias          (residual stream update, in place)
+  EPI_PATCH_F32 = 3,  // C(f32)[m + m/P + 1] = acc + pos[(m % P) + 1]   (patch embedding into the token stream)
+  EPI_STORE_F32 = 4,  // C(f32) = alpha * acc (+ bias if given)
+};
+
+struct GemmArgs {
+  const void* A;      // T [M, lda]
+  const void* W;      // T [N, ldw]
+  const float* bias;  // [N] or nullptr
+  void* C;            // [M(+), ldc]
+  const float* aux;   // EPI_PATCH_F32: positional embedding [P + 1, N]
+  float alpha;        // EPI_STORE_F32
+  int M, N, K;
+  int lda, ldw, ldc;  // in elements
+  int P;              // EPI_PATCH_F32: patches per image
+};
+
+// tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)
+int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------- attention
+// qkv: T [n_seq * S, 3 * D] (q | k | v, heads of 64 inside each), out: T [n_seq * S, D]
+int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S, int heads, int causal,
+                     hipStream_t stream);
+
+// --------------------------------------------------------------------------------------------- row ops
+// y[i] = LN(x[row(i)]) * gamma + beta.  row(i) = gather ? gather[i] : i; x row r at x + r * x_stride.
+// out_kind: 0 = f32, 1 = bf16.
+int launch_layernorm(const float* x, long x_stride, const int* gather, const float* gamma, const float* beta,
+                     void* y, long y_stride, int out_kind, int rows, int D, hipStream_t stream);
+int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream);
+int launch_cls_pos(float* x, const float* cls, const float* pos, int n, int tokens, int D, hipStream_t stream);
+int launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int* eot, int n, int L,
+                      int D, int vocab, hipStream_t stream);
+int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int frames, int dim, hipStream_t stream);
+int launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t stream);
+int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream_t stream);
+int launch_transpose_convert(const float* in, void* out, int out_kind, int rows, int cols, hipStream_t stream);
+int launch_wise(const float* a, const float* b, double w, float* out, size_t n, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- score
+int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, int32_t* ranks,
+                 hipStream_t stream);
+int launch_nce_loss(const float* scores, int n, float* out, float* ws, hipStream_t stream);
+int launch_kd_loss(const float* scores, const float* teacher, int n, float* out, float* ws, hipStream_t stream);
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace fc

@@ -1,0 +1,333 @@
+// HBM-bound row kernels around the GEMMs: LayerNorm, patch extraction, embeddings, pooling, conversions, WiSE.
+// All are one-wave-per-row or flat grid-stride kernels with 16-byte accesses (guide: Appendix B, Guideline 13).
+#include "common.h"
+#include <climits>
+
+namespace fc {
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;  // grid-stride cap (Guideline 11)
+
+template <typename OutT> __device__ __forceinline__ void put(OutT* p, float v);
+template <> __device__ __forceinline__ void put<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void put<bf16>(bf16* p, float v) { *p = static_cast<bf16>(v); }
+
+template <typename OutT> __device__ __forceinline__ void put4(OutT* p, const f32x4& v);
+template <> __device__ __forceinline__ void put4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void put4<bf16>(bf16* p, const f32x4& v) {
+  bf16x4 o;
+  o[0] = static_cast<bf16>(v[0]); o[1] = static_cast<bf16>(v[1]);
+  o[2] = static_cast<bf16>(v[2]); o[3] = static_cast<bf16>(v[3]);
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+// One wave per row, the row lives in registers (D / 64 floats per lane), two-pass mean / centred variance in fp32
+// (reference: slip.py:350-356 computes LayerNorm in float32, eps 1e-5).
+template <int D, typename OutT>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, long x_stride,
+                                                        const int* __restrict__ gather,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, OutT* __restrict__ y,
+                                                        long y_stride, int rows) {
+  constexpr int V4 = D / 256;          // float4 per lane (D multiple of 256) ...
+  constexpr int REM = (D % 256) / 64;  // ... plus scalars for D = 128 style widths
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+    const long src = gather ? gather[row] : row;
+    const float* xr = x + src * x_stride;
+    f32x4 v[V4 > 0 ? V4 : 1];
+    float s[REM > 0 ? REM : 1];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      s[i] = xr[V4 * 256 + i * 64 + lane];
+      sum += s[i];
+    }
+    const float mean = wave_sum(sum) * (1.f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] -= mean;
+        sq += v[i][e] * v[i][e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      s[i] -= mean;
+      sq += s[i] * s[i];
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / D) + 1e-5f);
+    OutT* yr = y + (long)row * y_stride;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      const int c = i * 256 + lane * 4;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * g4[e] + b4[e];
+      put4<OutT>(yr + c, o);
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      const int c = V4 * 256 + i * 64 + lane;
+      put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+    }
+  }
+}
+
+template <typename OutT>
+int layernorm_dispatch(const float* x, long xs, const int* gather, const float* g, const float* b, void* y, long ys,
+                       int rows, int D, hipStream_t st) {
+  const int blocks = min((rows + 3) / 4, kMaxBlocks);
+  OutT* yo = reinterpret_cast<OutT*>(y);
+  switch (D) {
+    case 128: hipLaunchKernelGGL((layernorm_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
+    case 256: hipLaunchKernelGGL((layernorm_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
+    case 512: hipLaunchKernelGGL((layernorm_kernel<512, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
+    case 768: hipLaunchKernelGGL((layernorm_kernel<768, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
+    case 1024: hipLaunchKernelGGL((layernorm_kernel<1024, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
+    default: return fail(FC_EINVAL, "layernorm: unsupported width %d", D);
+  }
+  FC_CHECK_LAUNCH("layernorm");
+  return FC_OK;
+}
+
+// ------------------------------------------------------------------------------------------- patch extraction
+// frames f32 [n, 3, R, R] -> patches T [n * g * g, 3 * p * p] with k = c * p * p + py * p + px (the flattening of
+// conv1.weight [width, 3, p, p]).  Each thread moves 4 consecutive pixels of one patch row (16-byte read).
+template <typename OutT>
+__global__ void __launch_bounds__(256) im2col_kernel(const float* __restrict__ frames, OutT* __restrict__ out, int n,
+                                                     int R, int p) {
+  const int g = R / p;
+  const long total4 = (long)n * 3 * R * R / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int x = (int)(e % R);
+    const int y = (int)((e / R) % R);
+    const int c = (int)((e / ((long)R * R)) % 3);
+    const long img = e / ((long)3 * R * R);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(frames + e);
+    const int gy = y / p, py = y - gy * p, gx = x / p, px = x - gx * p;
+    const long row = img * g * g + gy * g + gx;
+    put4<OutT>(out + row * (3L * p * p) + c * p * p + py * p + px, v);
+  }
+}
+
+__global__ void __launch_bounds__(256) cls_pos_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                      const float* __restrict__ pos, int n, int tokens, int D) {
+  const long total = (long)n * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const long img = i / D;
+    x[img * tokens * D + d] = cls[d] + pos[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------- text embedding
+// x[n, l, :] = token_embedding[ids[n, l]] + positional_embedding[l]; eot[n] = n * L + argmax(ids[n, :]) (first
+// maximum, as torch.argmax; reference slip.py:469-470,478).  One block per text.
+__global__ void __launch_bounds__(256) text_embed_kernel(const int64_t* __restrict__ ids,
+                                                         const float* __restrict__ tok,
+                                                         const float* __restrict__ pos, float* __restrict__ x,
+                                                         int* __restrict__ eot, int L, int D, int vocab) {
+  const int n = blockIdx.x;
+  const int64_t* row = ids + (long)n * L;
+  if (threadIdx.x < 64) {
+    long long best = LLONG_MIN;
+    int besti = 0x7fffffff;
+    for (int l = threadIdx.x; l < L; l += 64) {
+      const long long v = row[l];
+      if (v > best) { best = v; besti = l; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (threadIdx.x == 0) eot[n] = n * L + besti;
+  }
+  const int d4 = D / 4;
+  for (int i = threadIdx.x; i < L * d4; i += blockDim.x) {
+    const int l = i / d4, c = (i - l * d4) * 4;
+    long id = row[l];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never read outside the table
+    const f32x4 t = *reinterpret_cast<const f32x4*>(tok + id * D + c);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long)l * D + c);
+    *reinterpret_cast<f32x4*>(x + ((long)n * L + l) * D + c) = t + p;
+  }
+}
+
+// ------------------------------------------------------------------------------------- pooling / normalisation
+// out[b] = mean_f( e[b, f] / ||e[b, f]|| )   (clip_video_text_encoder.py:85,89: NOT re-normalised).  Block per clip.
+__global__ void __launch_bounds__(256) pool_normalize_kernel(const float* __restrict__ e, float* __restrict__ out,
+                                                             int frames, int dim) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int per = (dim + 255) / 256;  // <= 4 for dim <= 1024
+  float accv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < frames; ++f) {
+    const float* r = e + ((long)b * frames + f) * dim;
+    float v[4], sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256;
+      v[i] = (i < per && c < dim) ? r[c] : 0.f;
+      sq += v[i] * v[i];
+    }
+    sq = wave_sum(sq);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accv[i] += v[i] / nrm;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    if (i < per && c < dim) out[(long)b * dim + c] = frames == 1 ? accv[i] : accv[i] / (float)frames;
+  }
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256) convert_kernel(const float* __restrict__ in, OutT* __restrict__ out, size_t n4,
+                                                      size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    put4<OutT>(out + i * 4, *reinterpret_cast<const f32x4*>(in + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) put<OutT>(out + n4 * 4 + threadIdx.x, in[n4 * 4 + threadIdx.x]);
+}
+
+// out[c, r] = in[r, c]  (weight packing of visual.proj / text_projection: [K, N] -> [N, K]); tiny, run once.
+template <typename OutT>
+__global__ void __launch_bounds__(256) transpose_convert_kernel(const float* __restrict__ in, OutT* __restrict__ out,
+                                                                int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(long)(by + j) * cols + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < cols && by + tx < rows) put<OutT>(out + (long)(bx + j) * rows + by + tx, tile[tx][j]);
+}
+
+// out = (1 - w) * a + w * b   (aligner/wise.py:16), evaluated exactly as torch does: two roundings of the products
+// then one add (no fma contraction), so the result is bit-identical to the reference expression.
+__global__ void __launch_bounds__(256) wise_kernel(const float* __restrict__ a, const float* __restrict__ b, float w1,
+                                                   float w2, float* __restrict__ out, size_t n4, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a + i * 4);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(b + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(w1, x[e]), __fmul_rn(w2, y[e]));
+    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    out[i] = __fadd_rn(__fmul_rn(w1, a[i]), __fmul_rn(w2, b[i]));
+  }
+}
+
+inline int flat_blocks(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
+}
+
+}  // namespace
+
+int launch_layernorm(const float* x, long x_stride, const int* gather, const float* gamma, const float* beta, void* y,
+                     long y_stride, int out_kind, int rows, int D, hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  if ((x_stride % 4) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
+    return fail(FC_EINVAL, "layernorm: operands must be 16-byte aligned");
+  return out_kind == 1 ? layernorm_dispatch<bf16>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream)
+                       : layernorm_dispatch<float>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
+}
+
+int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream) {
+  if (n <= 0) return FC_OK;
+  if (res % patch || patch % 4) return fail(FC_EINVAL, "im2col: resolution %d / patch %d", res, patch);
+  const int blocks = flat_blocks((size_t)n * 3 * res * res / 4);
+  if (out_kind == 1)
+    hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, frames, (bf16*)patches, n, res, patch);
+  else
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, stream, frames, (float*)patches, n, res, patch);
+  FC_CHECK_LAUNCH("im2col");
+  return FC_OK;
+}
+
+int launch_cls_pos(float* x, const float* cls, const float* pos, int n, int tokens, int D, hipStream_t stream) {
+  if (n <= 0) return FC_OK;
+  hipLaunchKernelGGL(cls_pos_kernel, dim3(flat_blocks((size_t)n * D)), dim3(256), 0, stream, x, cls, pos, n, tokens, D);
+  FC_CHECK_LAUNCH("cls_pos");
+  return FC_OK;
+}
+
+int launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int* eot, int n, int L, int D,
+                      int vocab, hipStream_t stream) {
+  if (n <= 0) return FC_OK;
+  if (D % 4) return fail(FC_EINVAL, "text_embed: width %d", D);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(n), dim3(256), 0, stream, ids, tok, pos, x, eot, L, D, vocab);
+  FC_CHECK_LAUNCH("text_embed");
+  return FC_OK;
+}
+
+int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int frames, int dim, hipStream_t stream) {
+  if (n_clips <= 0) return FC_OK;
+  if (frames <= 0 || dim <= 0 || dim > 1024) return fail(FC_EINVAL, "pool_normalize: frames=%d dim=%d", frames, dim);
+  hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_clips), dim3(256), 0, stream, frame_emb, out, frames, dim);
+  FC_CHECK_LAUNCH("pool_normalize");
+  return FC_OK;
+}
+
+int launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t stream) {
+  return launch_pool_normalize(in, out, n, 1, dim, stream);
+}
+
+int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream_t stream) {
+  if (n == 0) return FC_OK;
+  const size_t n4 = n / 4;
+  const int blocks = flat_blocks(n4 ? n4 : 1);
+  if (out_kind == 1)
+    hipLaunchKernelGGL(convert_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, in, (bf16*)out, n4, n);
+  else
+    hipLaunchKernelGGL(convert_kernel<float>, dim3(blocks), dim3(256), 0, stream, in, (float*)out, n4, n);
+  FC_CHECK_LAUNCH("convert");
+  return FC_OK;
+}
+
+int launch_transpose_convert(const float* in, void* out, int out_kind, int rows, int cols, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return FC_OK;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  if (out_kind == 1)
+    hipLaunchKernelGGL(transpose_convert_kernel<bf16>, grid, dim3(256), 0, stream, in, (bf16*)out, rows, cols);
+  else
+    hipLaunchKernelGGL(transpose_convert_kernel<float>, grid, dim3(256), 0, stream, in, (float*)out, rows, cols);
+  FC_CHECK_LAUNCH("transpose_convert");
+  return FC_OK;
+}
+
+int launch_wise(const float* a, const float* b, double w, float* out, size_t n, hipStream_t stream) {
+  if (n == 0) return FC_OK;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return fail(FC_EINVAL, "wise: unaligned operand");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(wise_kernel, dim3(flat_blocks(n4 ? n4 : 1)), dim3(256), 0, stream, a, b, (float)(1.0 - w),
+                     (float)w, out, n4, n);
+  FC_CHECK_LAUNCH("wise");
+  return FC_OK;
+}
+
+}  // namespace fc

@@ -1,0 +1,82 @@
+"""Multi-GPU glue of the encode-and-score path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" on CPU for the tests).
+
+The path shards by clip: every rank encodes a contiguous block of clips and their captions, then ONE exchange step -
+an all-gather of the [N/world, 512] fp32 embeddings (2 MiB per rank per tensor at N = 8192: latency-bound, done once
+after the whole shard is encoded, never per batch) - after which each rank scores its own text rows against all
+videos and the integer hit counts are all-reduced.  This is what the reference does through
+`util/tensor_utils.all_gather` (:48-66) + torchmetrics' `dist_reduce_fx="cat"` (`aligner/metrics.py:13`), minus the
+padding / duplication of its DDP sampler (the shards here are exact).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, exact partition of range(n): the first n % world ranks hold one extra item."""
+    base, extra = divmod(n, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_counts(n: int, world_size: int) -> List[int]:
+    return [shard_bounds(n, world_size, r)[1] - shard_bounds(n, world_size, r)[0] for r in range(world_size)]
+
+
+def all_gather_rows(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
+    """Concatenation over ranks of `local` ([counts[rank], ...]), in rank order - the flattened
+    `[world, B, ...] -> [world * B, ...]` view of the reference wrapper (tensor_utils.py:58-60), for ragged shards."""
+    rank, world_size = world()
+    if world_size == 1:
+        return local
+    assert local.shape[0] == counts[rank], (local.shape, counts, rank)
+    biggest = max(counts)
+    padded = local
+    if local.shape[0] != biggest:
+        padded = local.new_zeros((biggest, *local.shape[1:]))
+        padded[:local.shape[0]] = local
+    gathered = local.new_empty((world_size * biggest, *local.shape[1:]))
+    dist.all_gather_into_tensor(gathered, padded.contiguous())
+    if all(c == biggest for c in counts):
+        return gathered
+    return torch.cat([gathered[r * biggest: r * biggest + c] for r, c in enumerate(counts)])
+
+
+def metrics_from_ranks(ranks: np.ndarray) -> Dict[str, float]:
+    """R@1/5/10 = fraction of ranks < k (torchmetrics Recall(top_k), text_video_retrieval.py:21); MedianRank =
+    lower-middle median + 1 (torch.median semantics, aligner/metrics.py:33-36)."""
+    ranks = np.asarray(ranks).astype(np.int64)
+    if ranks.size == 0:
+        return {"r1": float("nan"), "r5": float("nan"), "r10": float("nan"), "mr": float("nan")}
+    out = {f"r{k}": float((ranks < k).mean()) for k in (1, 5, 10)}
+    out["mr"] = float(np.sort(ranks)[(ranks.size - 1) // 2] + 1)
+    return out
+
+
+def sharded_retrieval(local_videos: torch.Tensor, local_texts: torch.Tensor, n_total: int,
+                      similarity: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+                      ranks_of: Callable[[torch.Tensor, int], torch.Tensor]) -> Dict[str, float]:
+    """Epoch-end scoring (text_video_retrieval.py:67-83) over embeddings sharded by clip.
+
+    `similarity(T_local, V_all)` -> [n_local, n_total] scores; `ranks_of(scores, offset)` -> rank of column
+    `offset + i` in row i.  Both are the HIP operators in production; the CPU tests inject the oracle's.
+    """
+    rank, world_size = world()
+    counts = shard_counts(n_total, world_size)
+    start, _ = shard_bounds(n_total, world_size, rank)
+    all_videos = all_gather_rows(local_videos, counts)
+    scores = similarity(local_texts, all_videos)
+    local_ranks = ranks_of(scores, start).to(torch.int32)
+    all_ranks = all_gather_rows(local_ranks, counts)
+    return metrics_from_ranks(all_ranks.cpu().numpy())

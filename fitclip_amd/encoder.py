@@ -1,0 +1,119 @@
+"""`ClipVideoTextEncoder`: the reference's CLIP encoder plugin (`aligner/encoder/clip_video_text_encoder.py:68-146`)
+on the HIP path.  Constructor `(model, num_frames=4)`, `encode_video` / `encode_text` / `forward(video, text)`, the
+tokenizer / transform / frame-sampler factories and `should_pad_batch` have the reference's meaning, so it can be the
+`_target_` of `config/encoder/clip.yaml` and the `model1` / `model2` of `config/encoder/wise.yaml`.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Iterable, Iterator, Mapping
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .clip_model import CLIP
+from .frame_sampler import FrameSampler, RandomFromUniformIntervalsFrameSampler, UniformFrameSampler
+from .plugin_api import (TYPE_TEXT_INPUT, TYPE_TOKENIZER, TYPE_TRANSFORM, TYPE_VIDEO_INPUT, VideoTextEncoder,
+                         float_standard_denormalize)
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)  # clip_video_text_encoder.py:72
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class HashTokenizer:
+    """Stand-in for `clip.tokenize(texts, truncate=True)` (clip_video_text_encoder.py:64-65).
+
+    The CLIP BPE vocabulary file is not available offline, so words are mapped to ids in
+    [1, SOT) with a CRC; the FRAMING is the real one: SOT, tokens, EOT (the largest id, which `encode_text` locates
+    with argmax), zero padding, truncation that keeps EOT last.
+    """
+
+    def __init__(self, context_length: int, vocab_size: int) -> None:
+        self.context_length, self.vocab_size = context_length, vocab_size
+
+    def __call__(self, texts: Iterable[str]) -> Mapping[str, torch.Tensor]:
+        sot, eot = self.vocab_size - 2, self.vocab_size - 1
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        ids = torch.zeros((len(texts), self.context_length), dtype=torch.long)
+        for i, text in enumerate(texts):
+            toks = [sot] + [1 + zlib.crc32(w.encode()) % (sot - 1) for w in text.lower().split()] + [eot]
+            if len(toks) > self.context_length:
+                toks = toks[:self.context_length]
+                toks[-1] = eot
+            ids[i, :len(toks)] = torch.tensor(toks)
+        return {"input_ids": ids}
+
+
+class ClipVideoTextEncoder(VideoTextEncoder):
+    def __init__(self, model: CLIP, num_frames: int = 4) -> None:
+        super().__init__()
+        self.model = model
+        self.num_frames = num_frames
+        self.mean, self.std = CLIP_MEAN, CLIP_STD
+        # Same as the reference (:75-77): the CLIP temperature is unused, drop the parameter so it is not in
+        # `named_parameters()` (WiSE) nor in the optimiser.
+        if hasattr(self.model, "logit_scale"):
+            delattr(self.model, "logit_scale")
+
+    def encode_video(self, video: TYPE_VIDEO_INPUT) -> torch.Tensor:
+        """f32 [B, F, 3, H, W] -> f32 [B, E]: every frame through the visual tower, unit-normalise each frame
+        embedding, average over the F frames (not re-normalised) - reference :80-89."""
+        batch_size = video.shape[0]
+        images = video.reshape(-1, *video.shape[2:])
+        frame_features = self.model.encode_image(images)
+        frames = images.shape[0] // batch_size if batch_size else 1
+        return ops.pool_normalize(frame_features, batch_size, frames)
+
+    def encode_text(self, text: TYPE_TEXT_INPUT) -> torch.Tensor:
+        """{"input_ids": int [B, 77]} -> unit-norm f32 [B, E] - reference :92-94."""
+        return ops.l2_normalize(self.model.encode_text(text["input_ids"]))
+
+    def get_tokenizer(self) -> TYPE_TOKENIZER:
+        return HashTokenizer(self.model.context_length, self.model.vocab_size)
+
+    def decode_text(self, text: TYPE_TEXT_INPUT) -> Iterator[str]:
+        for ids in text["input_ids"]:
+            yield " ".join(f"<{int(t)}>" for t in ids if int(t) != 0)
+
+    def get_train_frame_sampler(self) -> FrameSampler:
+        return RandomFromUniformIntervalsFrameSampler(self.num_frames)
+
+    def get_eval_frame_sampler(self) -> FrameSampler:
+        return UniformFrameSampler(self.num_frames)
+
+    def _normalize(self, v: torch.Tensor) -> torch.Tensor:
+        mean = torch.as_tensor(self.mean, dtype=v.dtype, device=v.device).view(-1, 1, 1)
+        std = torch.as_tensor(self.std, dtype=v.dtype, device=v.device).view(-1, 1, 1)
+        return (v - mean) / std
+
+    def get_eval_transform(self, dtype: torch.dtype) -> TYPE_TRANSFORM:
+        """uint8 [F, H, W, C] -> `dtype` [F, C, R, R]: BHWC->BCHW, /255, bicubic resize of the shorter side to R,
+        centre crop, CLIP mean/std (reference :125-133; data-side preprocessing, not part of the timed path)."""
+        size = self.model.visual.input_resolution
+
+        def transform(v: torch.Tensor) -> torch.Tensor:
+            v = v.permute(0, 3, 1, 2)
+            v = v.to(dtype) / 255 if not v.is_floating_point() else v.to(dtype)
+            h, w = v.shape[-2:]
+            scale = size / min(h, w)
+            nh, nw = max(size, round(h * scale)), max(size, round(w * scale))
+            v = F.interpolate(v, size=(nh, nw), mode="bicubic", align_corners=False, antialias=True)
+            top, left = (nh - size) // 2, (nw - size) // 2
+            return self._normalize(v[..., top:top + size, left:left + size])
+
+        return transform
+
+    def get_train_transform(self, dtype: torch.dtype) -> TYPE_TRANSFORM:
+        # Training augmentation (random resized crop + flip, reference :113-122) is outside this inference path.
+        return self.get_eval_transform(dtype)
+
+    @property
+    def should_pad_batch(self) -> bool:
+        return True
+
+    def to_bchw(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def denormalize_video_tensor(self, video: TYPE_VIDEO_INPUT) -> torch.Tensor:
+        return float_standard_denormalize(video, mean=self.mean, std=self.std)

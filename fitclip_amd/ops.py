@@ -1,0 +1,187 @@
+"""Python entry points of the single HIP operators (PyTorch-ROCm tensors in, tensors out).  Thin: every function
+checks shapes / dtypes / device, allocates the output with torch, and makes ONE C-ABI call on the current stream."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS_T, EPI_GELU_T, EPI_PATCH_F32, EPI_RESID_F32, EPI_STORE_F32, PREC_BF16, PREC_F32  # noqa
+
+_KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
+
+
+def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    if t.device.type != "cuda":
+        raise _lib.FitclipHipError(f"{name} must live on the ROCm device (got {t.device}); there is no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS_T,
+         out: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, alpha: float = 1.0, patches: int = 0,
+         tile: int = 0) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T).  a / w float32 (exact fp32 MFMA) or bfloat16."""
+    _dev(a, "a"), _dev(w, "w", a.dtype)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("inner dimensions differ")
+    f32_out = epilogue in (EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32)
+    if out is None:
+        if epilogue == EPI_RESID_F32:
+            raise ValueError("the residual epilogue accumulates into `out`")
+        rows = M + M // patches if epilogue == EPI_PATCH_F32 else M
+        out = torch.empty((rows, N), dtype=torch.float32 if f32_out else a.dtype, device=a.device)
+    _dev(out, "out", torch.float32 if f32_out else a.dtype)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().fc_gemm(_KIND[a.dtype], epilogue, a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(),
+                                       _ptr(aux), alpha, M, N, K, a.stride(0), w.stride(0), out.stride(0), patches,
+                                       tile, _lib.current_stream()), "fc_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype = torch.float32,
+              gather: Optional[torch.Tensor] = None, row_stride: Optional[int] = None, rows: Optional[int] = None
+              ) -> torch.Tensor:
+    _dev(x, "x", torch.float32), _dev(gamma, "gamma", torch.float32), _dev(beta, "beta", torch.float32)
+    D = gamma.numel()
+    row_stride = D if row_stride is None else row_stride
+    if gather is not None:
+        _dev(gather, "gather", torch.int32)
+        rows = gather.numel()
+    elif rows is None:
+        rows = x.numel() // row_stride
+    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().fc_layernorm(x.data_ptr(), row_stride, _ptr(gather), gamma.data_ptr(), beta.data_ptr(),
+                                            y.data_ptr(), D, _KIND[out_dtype], rows, D, _lib.current_stream()),
+                   "fc_layernorm")
+    return y
+
+
+def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False) -> torch.Tensor:
+    """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]."""
+    _dev(qkv, "qkv")
+    D = heads * 64
+    if qkv.shape != (n_seq * seq_len, 3 * D):
+        raise ValueError(f"qkv shape {tuple(qkv.shape)} != {(n_seq * seq_len, 3 * D)}")
+    out = torch.empty((n_seq * seq_len, D), dtype=qkv.dtype, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.load().fc_attention(_KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(), n_seq, seq_len, heads,
+                                            int(causal), _lib.current_stream()), "fc_attention")
+    return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, "x", torch.float32)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().fc_convert(x.data_ptr(), out.data_ptr(), PREC_BF16, x.numel(), _lib.current_stream()),
+                   "fc_convert")
+    return out
+
+
+def pool_normalize(frame_emb: torch.Tensor, n_clips: int, frames: int) -> torch.Tensor:
+    """mean over frames of the L2-normalised frame embeddings (clip_video_text_encoder.py:85-89)."""
+    _dev(frame_emb, "frame_emb", torch.float32)
+    dim = frame_emb.shape[-1]
+    out = torch.empty((n_clips, dim), dtype=torch.float32, device=frame_emb.device)
+    if n_clips:
+        with torch.cuda.device(frame_emb.device):
+            _lib.check(_lib.load().fc_pool_normalize(frame_emb.data_ptr(), out.data_ptr(), n_clips, frames, dim,
+                                                     _lib.current_stream()), "fc_pool_normalize")
+    return out
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, "x", torch.float32)
+    out = torch.empty_like(x)
+    if x.shape[0]:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fc_l2_normalize(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                                   _lib.current_stream()), "fc_l2_normalize")
+    return out
+
+
+def similarity(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """alpha * a @ b^T in exact fp32 (text_video_retrieval.py:50,74)."""
+    _dev(a, "a", torch.float32), _dev(b, "b", torch.float32)
+    na, nb = a.shape[0], b.shape[0]
+    ld = (nb + 3) // 4 * 4
+    buf = torch.empty((na, ld), dtype=torch.float32, device=a.device)
+    if na and nb:
+        bb = b
+        if nb != ld:  # the kernel writes 4 columns at a time: pad B's rows, drop the extra columns afterwards
+            bb = torch.zeros((ld, b.shape[1]), dtype=torch.float32, device=b.device)
+            bb[:nb] = b
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.load().fc_similarity(a.data_ptr(), bb.data_ptr(), na, ld, a.shape[1], alpha, buf.data_ptr(),
+                                                 ld, _lib.current_stream()), "fc_similarity")
+    return buf[:, :nb]
+
+
+def ranks(scores: torch.Tensor, target_offset: int = 0) -> torch.Tensor:
+    """Position of column (i + target_offset) in the stable descending order of row i (aligner/metrics.py:16-20)."""
+    if scores.device.type != "cuda" or scores.dtype != torch.float32 or scores.stride(1) != 1:
+        raise _lib.FitclipHipError("scores must be a float32 ROCm tensor with unit column stride")
+    n_rows, n_cols = scores.shape
+    out = torch.empty((n_rows,), dtype=torch.int32, device=scores.device)
+    if n_rows:
+        with torch.cuda.device(scores.device):
+            _lib.check(_lib.load().fc_ranks(scores.data_ptr(), scores.stride(0), n_rows, n_cols, target_offset,
+                                            out.data_ptr(), _lib.current_stream()), "fc_ranks")
+    return out
+
+
+def _square(scores: torch.Tensor, name: str) -> torch.Tensor:
+    scores = _dev(scores.contiguous(), name, torch.float32)
+    if scores.dim() != 2 or scores.shape[0] != scores.shape[1]:
+        raise ValueError(f"{name} must be square")
+    return scores
+
+
+def nce_loss(scores: torch.Tensor) -> torch.Tensor:
+    """aligner/loss.py:13-26, reduction "mean"."""
+    scores = _square(scores, "scores")
+    n = scores.shape[0]
+    out = torch.empty((1,), dtype=torch.float32, device=scores.device)
+    ws = torch.empty((2 * n,), dtype=torch.float32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().fc_nce_loss(scores.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _lib.current_stream()),
+                   "fc_nce_loss")
+    return out[0]
+
+
+def teacher_student_nce_loss(scores: torch.Tensor, teacher_scores: torch.Tensor) -> torch.Tensor:
+    """aligner/loss.py:29-39 with reduction "batchmean" (teacher_student.py:72-73)."""
+    scores, teacher_scores = _square(scores, "scores"), _square(teacher_scores, "teacher_scores")
+    n = scores.shape[0]
+    out = torch.empty((1,), dtype=torch.float32, device=scores.device)
+    ws = torch.empty((2 * n,), dtype=torch.float32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().fc_kd_loss(scores.data_ptr(), teacher_scores.data_ptr(), n, out.data_ptr(),
+                                          ws.data_ptr(), _lib.current_stream()), "fc_kd_loss")
+    return out[0]
+
+
+def wise_axpby(a: torch.Tensor, b: torch.Tensor, weight_for_2: float, out: Optional[torch.Tensor] = None
+               ) -> torch.Tensor:
+    """(1 - w) * a + w * b (aligner/wise.py:16)."""
+    _dev(a, "a", torch.float32), _dev(b, "b", torch.float32)
+    if a.shape != b.shape:
+        raise ValueError("shape mismatch")
+    out = torch.empty_like(a) if out is None else out
+    if a.numel():
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.load().fc_wise(a.data_ptr(), b.data_ptr(), float(weight_for_2), out.data_ptr(), a.numel(),
+                                           _lib.current_stream()), "fc_wise")
+    return out

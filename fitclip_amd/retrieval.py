@@ -1,0 +1,112 @@
+"""`command=evaluate` semantics without Lightning: the three hooks of the reference's retrieval module
+(`aligner/text_video_retrieval.py:40-98` on top of `aligner/video_text_module.py:25-76`) as plain methods.
+
+    module = TextVideoRetrievalModule(encoder, init_temperature=0.015)         # config/trainer.yaml:17-20
+    for batch in loader:  out = module.validation_step(batch); module.validation_step_end(out)
+    metrics = module.validation_epoch_end()   # {"loss/val", "r1", "r5", "r10", "mr"}
+
+All tensor arithmetic (encoders, score matrices, losses, ranks) runs in the HIP library.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, MutableMapping, Optional, Tuple
+
+import torch
+
+from . import distributed as D
+from . import ops
+from .plugin_api import TYPE_OUTPUT, VideoTextEncoder
+
+TYPE_INPUT = MutableMapping[str, Any]
+
+
+class VideoTextModule:
+    def __init__(self, encoder: VideoTextEncoder, init_temperature: float = 0.05,
+                 min_temperature: float = 0.001) -> None:
+        self.encoder = encoder
+        self.logit_scale = -math.log(init_temperature)          # video_text_module.py:32
+        self.max_logit_scale = -math.log(min_temperature)
+
+    def forward(self, batch: TYPE_INPUT) -> TYPE_OUTPUT:
+        batch.pop("video_id", None)                              # video_text_module.py:40-41
+        return self.encoder(**batch)
+
+    __call__ = forward
+
+    def step_scores(self, encoded_video: torch.Tensor, encoded_text: torch.Tensor) -> torch.Tensor:
+        """logit_scale.exp() * V @ T^T (video_text_module.py:62-63)."""
+        scale = math.exp(min(self.logit_scale, self.max_logit_scale))
+        return ops.similarity(encoded_video, encoded_text, alpha=scale)
+
+    def predict_step(self, batch: TYPE_INPUT) -> Dict[str, Any]:
+        video_ids = batch.get("video_id")
+        encoded_video, encoded_text = self(dict(batch))
+        return {"encoded_videos": encoded_video, "encoded_texts": encoded_text, "video_ids": video_ids}
+
+
+class TextVideoRetrievalModule(VideoTextModule):
+    def __init__(self, encoder: VideoTextEncoder, init_temperature: float = 0.05, min_temperature: float = 0.001,
+                 n_total: Optional[int] = None) -> None:
+        super().__init__(encoder, init_temperature, min_temperature)
+        self.n_total = n_total
+        self._outputs: List[TYPE_OUTPUT] = []
+        self._losses: List[Tuple[float, int]] = []
+
+    def validation_step(self, batch: TYPE_INPUT) -> TYPE_OUTPUT:
+        return self(batch)
+
+    def validation_step_end(self, output: TYPE_OUTPUT) -> TYPE_OUTPUT:
+        """Per-batch `loss/val` = NCE(exp(logit_scale) V T^T) on the batch (text_video_retrieval.py:44-58).  The
+        reference gathers the batch across DDP ranks first; with exact clip shards every rank logs its own batches
+        and the epoch-level mean is all-reduced instead."""
+        encoded_video, encoded_text = output
+        loss = ops.nce_loss(self.step_scores(encoded_video, encoded_text))
+        self._losses.append((float(loss), len(encoded_video)))
+        self._outputs.append(output)
+        return output
+
+    def validation_epoch_end(self) -> Dict[str, float]:
+        """cat all batches, scores = T @ V^T, target = arange, R@1/5/10 + median rank
+        (text_video_retrieval.py:67-83)."""
+        encoded_videos = torch.cat([o[0] for o in self._outputs])
+        encoded_texts = torch.cat([o[1] for o in self._outputs])
+        rank, world_size = D.world()
+        n_total = self.n_total if self.n_total is not None else len(encoded_videos) * world_size
+        metrics = D.sharded_retrieval(encoded_videos, encoded_texts, n_total, ops.similarity,
+                                      lambda s, off: ops.ranks(s, off))
+        num = torch.tensor([sum(l * b for l, b in self._losses), float(sum(b for _, b in self._losses))],
+                           dtype=torch.float64, device=encoded_videos.device)
+        if world_size > 1:
+            torch.distributed.all_reduce(num)
+        metrics["loss/val"] = float(num[0] / num[1])
+        self._outputs, self._losses = [], []
+        return metrics
+
+
+class TeacherStudentModule(VideoTextModule):
+    """Forward + loss value of the distillation module (`aligner/teacher_student.py:93-96,142-173`); no backward."""
+
+    def __init__(self, encoder: VideoTextEncoder, teacher: VideoTextEncoder, init_temperature: float = 0.05,
+                 min_temperature: float = 0.001) -> None:
+        super().__init__(encoder, init_temperature, min_temperature)
+        self.teacher = teacher
+        self.teacher_student_logit_scale = self.logit_scale       # teacher_student.py:68-69
+
+    def step(self, batch: TYPE_INPUT) -> Tuple[TYPE_OUTPUT, TYPE_OUTPUT]:
+        return (self.encoder(video=batch["video_student"], text=batch["text_student"]),
+                self.teacher(video=batch["video_teacher"], text=batch["text_teacher"]))
+
+    def dataset_step_end(self, output: Tuple[TYPE_OUTPUT, TYPE_OUTPUT], labeled: bool) -> torch.Tensor:
+        (video, text), (teacher_video, teacher_text) = output
+        rank, world_size = D.world()
+        if world_size > 1:
+            counts = [len(video)] * world_size  # training batches are equal-sized per rank (DDP)
+            video, text, teacher_video, teacher_text = (D.all_gather_rows(t, counts) for t in
+                                                        (video, text, teacher_video, teacher_text))
+        scores = self.step_scores(video, text)
+        if labeled:
+            return ops.nce_loss(scores)
+        ts_scale = math.exp(self.teacher_student_logit_scale)
+        teacher_scores = ops.similarity(teacher_video, teacher_text, alpha=ts_scale)
+        return ops.teacher_student_nce_loss(scores, teacher_scores) * ts_scale ** 2

@@ -1,0 +1,151 @@
+/* fitclip_hip.h - C ABI of libfitclip_hip.so: the MI355X (gfx950) encode-and-score path of FitCLIP.
+ *
+ * The reference (bryant1410/fitclip) has no FFI: its hot path is Python calling `clip.model.CLIP.encode_image /
+ * encode_text` (third-party openai/CLIP) from `aligner/encoder/clip_video_text_encoder.py`.  This header is the C
+ * boundary a binding for that path would use; each entry point names the reference code it replaces (paths relative
+ * to the reference repository root).  INTEGRATION.md shows the ctypes / cffi stub for the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer marked "dev" is DEVICE memory owned by the caller (PyTorch-ROCm
+ *     tensors: pass `tensor.data_ptr()`); the library allocates no device memory and never synchronises.
+ *   - every launch goes to the `hipStream_t` passed in (`torch.cuda.current_stream().cuda_stream`); all functions
+ *     may be captured into a hipGraph.
+ *   - return 0 on success, a negative fc_status otherwise; `fc_last_error()` returns a thread-local message.
+ *   - one handle per device / model; handles are independent (no global state besides the error string).
+ *   - layouts: row-major, fp32 unless stated; video frames NCHW fp32 (the layout the reference's eval transform
+ *     produces, clip_video_text_encoder.py:125-133); token ids int64 [n, context_length] (clip.tokenize output).
+ */
+#ifndef FITCLIP_HIP_H
+#define FITCLIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(FITCLIP_BUILD)
+#define FC_API __attribute__((visibility("default")))
+#else
+#define FC_API
+#endif
+
+typedef struct ihipStream_t* fc_stream; /* == hipStream_t */
+
+typedef enum {
+  FC_OK = 0,
+  FC_EINVAL = -1,  /* bad argument (shape, alignment, unknown name) */
+  FC_ELAUNCH = -2, /* HIP launch / runtime error */
+  FC_ENOMEM = -3,  /* workspace or arena too small */
+  FC_ESTATE = -4   /* call order (weights missing / not packed) */
+} fc_status;
+
+typedef enum {
+  FC_PREC_F32 = 0, /* exact fp32: v_mfma_f32_16x16x4_f32 GEMMs, fp32 activations (parity path)                */
+  FC_PREC_BF16 = 1 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream / LayerNorm / softmax          */
+} fc_precision;
+
+/* Architecture: the keys of config/encoder/clip_from_scratch_vit_b_16.yaml:5-16 (heads = width / 64 as in
+ * clip.model.CLIP).  Head dimension must be 64. */
+typedef struct {
+  int32_t embed_dim;          /* 512  */
+  int32_t image_resolution;   /* 224  */
+  int32_t vision_layers;      /* 12   */
+  int32_t vision_width;       /* 768  */
+  int32_t vision_patch_size;  /* 16   */
+  int32_t context_length;     /* 77   */
+  int32_t vocab_size;         /* 49408 */
+  int32_t transformer_width;  /* 512  */
+  int32_t transformer_heads;  /* 8    */
+  int32_t transformer_layers; /* 12   */
+  int32_t precision;          /* fc_precision */
+  int32_t chunk_frames;       /* frames per pass of the visual tower; 0 = default */
+  int32_t chunk_texts;        /* texts per pass of the text tower;    0 = default */
+  int32_t gemm_tile;          /* 0 = auto, 1 = 128x128, 2 = 256x256 (tuning / tests) */
+} fc_config;
+
+typedef struct fc_handle fc_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+FC_API int fc_create(const fc_config* cfg, fc_handle** out);
+FC_API void fc_destroy(fc_handle* h);
+FC_API const char* fc_last_error(void);
+FC_API const char* fc_version(void);
+
+/* ---- weights: replaces `clip.load(...)` + `load_state_dict` (clip_video_text_encoder.py:22-61) ----------------
+ * `name` is the OpenAI-CLIP state-dict key ("visual.conv1.weight", "transformer.resblocks.3.attn.in_proj_weight",
+ * "token_embedding.weight", ...; `logit_scale`, `input_resolution`, `context_length`, `vocab_size` are accepted and
+ * ignored).  `dev_f32` is BORROWED: it must stay valid (and may be updated in place, e.g. by WiSE) until the handle
+ * is destroyed; call fc_pack_weights again after changing values. */
+FC_API int fc_set_weight(fc_handle* h, const char* name, const float* dev_f32, const int64_t* shape, int32_t ndim);
+FC_API int fc_num_weights(const fc_handle* h);                       /* how many names fc_set_weight expects */
+FC_API const char* fc_weight_name(const fc_handle* h, int32_t index); /* the index-th expected name */
+/* Kernel-layout copies of the GEMM weights (bf16 conversion, [K,N] -> [N,K] transposes of the two projections). */
+FC_API size_t fc_packed_bytes(const fc_handle* h);
+FC_API int fc_pack_weights(fc_handle* h, void* dev_arena, size_t arena_bytes, fc_stream stream);
+
+/* ---- encoders -------------------------------------------------------------------------------------------------
+ * fc_encode_image: `CLIP.encode_image(images)` as called at clip_video_text_encoder.py:84.
+ *   frames dev f32 [n_frames, 3, R, R] -> out dev f32 [n_frames, embed_dim] (NOT normalised).
+ * fc_encode_text: `CLIP.encode_text(ids)` as called at clip_video_text_encoder.py:93 (in-tree twin
+ *   aligner/encoder/slip.py:468-480): ids dev int64 [n_texts, context_length] -> out dev f32 [n_texts, embed_dim].
+ * `workspace` is caller-owned scratch of at least fc_workspace_bytes(h, tower, n) bytes (tower 0 = visual, 1 = text);
+ * a smaller workspace is accepted as long as one chunk of at least one item fits (more passes). */
+FC_API size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n);
+FC_API int fc_encode_image(fc_handle* h, const float* frames, int32_t n_frames, float* out, void* workspace,
+                    size_t workspace_bytes, fc_stream stream);
+FC_API int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n_texts, float* out, void* workspace,
+                   size_t workspace_bytes, fc_stream stream);
+
+/* clip_video_text_encoder.py:85-89: out[b] = mean_f(e[b,f] / ||e[b,f]||), NOT re-normalised.  e [n_clips*frames, dim] */
+FC_API int fc_pool_normalize(const float* frame_emb, float* out, int32_t n_clips, int32_t frames, int32_t dim,
+                      fc_stream stream);
+/* clip_video_text_encoder.py:94: out[i] = in[i] / ||in[i]|| */
+FC_API int fc_l2_normalize(const float* in, float* out, int32_t n, int32_t dim, fc_stream stream);
+
+/* ---- scoring ---------------------------------------------------------------------------------------------------
+ * fc_similarity: out[na, nb] = alpha * A[na, dim] . B[nb, dim]^T in exact fp32 (text_video_retrieval.py:50,74;
+ *   video_text_module.py:63).  dim % 32 == 0, nb % 4 == 0, ldo >= nb.
+ * fc_ranks: ranks[i] = position of column (i + target_offset) in the stable descending order of row i
+ *   (aligner/metrics.py:16-20).  scores [n_rows, ld].
+ * fc_nce_loss / fc_kd_loss: aligner/loss.py:13-26 / 29-39 (KD with reduction="batchmean", teacher_student.py:72-73)
+ *   on square [n, n] matrices; `ws` dev f32 scratch of 2 * n floats; result in out[0]. */
+FC_API int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb, int32_t dim, float alpha, float* out,
+                  int32_t ldo, fc_stream stream);
+FC_API int fc_ranks(const float* scores, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t target_offset, int32_t* ranks,
+             fc_stream stream);
+FC_API int fc_nce_loss(const float* scores, int32_t n, float* out, float* ws, fc_stream stream);
+FC_API int fc_kd_loss(const float* scores, const float* teacher_scores, int32_t n, float* out, float* ws, fc_stream stream);
+
+/* ---- WiSE (aligner/wise.py:16): out = (1 - weight_for_2) * a + weight_for_2 * b over n floats ------------------ */
+FC_API int fc_wise(const float* a, const float* b, double weight_for_2, float* out, size_t n, fc_stream stream);
+
+/* ---- single operators (unit parity tests, tuning) --------------------------------------------------------------
+ * element kind: 0 = f32, 1 = bf16 (as fc_precision).  See csrc/common.h for the epilogue ids. */
+FC_API int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const void* W, const float* bias, void* C,
+            const float* aux, float alpha, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
+            int32_t P, int32_t tile, fc_stream stream);
+FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather, const float* gamma, const float* beta,
+                 void* y, int64_t y_stride, int32_t out_kind, int32_t rows, int32_t D, fc_stream stream);
+FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
+                 int32_t causal, fc_stream stream);
+FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
+
+/* ---- kernel timing (bench.py roofline leg): hipEvent pairs around every GEMM launch on the caller's stream ------ */
+typedef struct {
+  int32_t kind;      /* 0 = gemm */
+  int32_t precision; /* fc_precision */
+  int32_t epilogue;
+  int32_t tile;
+  int32_t M, N, K;
+  float ms;          /* elapsed between the two events; valid after the stream has been synchronised */
+} fc_prof_record;
+FC_API int fc_profile_enable(fc_handle* h, int32_t max_records); /* 0 disables and frees the events */
+FC_API int fc_profile_reset(fc_handle* h);
+FC_API int fc_profile_read(fc_handle* h, fc_prof_record* out, int32_t max_records); /* returns the record count */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FITCLIP_HIP_H */

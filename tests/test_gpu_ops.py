@@ -1,0 +1,155 @@
+"""GPU parity of the single HIP operators, called through the C ABI, against fp64 / oracle references on the same
+seeded inputs.  Tolerances are stated per test: the fp32 path is an exact-fp32 fma chain (summation-order noise only),
+the bf16 path rounds operands and stored activations to bf16 (relative 2^-9 per rounding)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fitclip_amd import ops  # noqa: E402
+from oracle import clip_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+GEMM_SHAPES = [(300, 256, 256, 1), (1000, 512, 768, 2), (37, 128, 3072, 1), (515, 768, 128, 2), (16, 132, 64, 1)]
+
+
+@pytest.mark.parametrize("M,N,K,tile", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_all_epilogues(M, N, K, tile, dtype):
+    a, w, bias = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    ad, wd = a.to(DEV).to(dtype), w.to(DEV).to(dtype)
+    a64, w64 = ad.double().cpu(), wd.double().cpu()  # the operands the kernel actually sees
+    ref = a64 @ w64.T
+    tol = 2e-6 if dtype == torch.float32 else 6e-3   # bf16: one output rounding (2^-9) on O(1) values
+    bd = bias.to(DEV)
+    out = ops.gemm(ad, wd, bd, ops.EPI_BIAS_T, tile=tile)
+    assert out.dtype == dtype and _rel(out, ref + bias.double()) < tol
+    out = ops.gemm(ad, wd, bd, ops.EPI_GELU_T, tile=tile)
+    z = ref + bias.double()
+    assert _rel(out, z * torch.sigmoid(1.702 * z)) < tol
+    resid = _rand(M, N, seed=4)
+    acc = resid.to(DEV).clone()
+    ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=tile)
+    assert _rel(acc, resid.double() + z) < (2e-6 if dtype == torch.float32 else 2e-6 + 0)
+    out = ops.gemm(ad, wd, None, ops.EPI_STORE_F32, alpha=0.5, tile=tile)
+    assert out.dtype == torch.float32 and _rel(out, 0.5 * ref) < 2e-6
+    if M % 4 == 0:
+        P = M // 4
+        pos = _rand(P + 1, N, seed=5).to(DEV)
+        out = ops.gemm(ad, wd, None, ops.EPI_PATCH_F32, aux=pos, patches=P, tile=tile,
+                       out=torch.full((M + 4, N), 7.0, device=DEV))
+        want = torch.full((4, P + 1, N), 7.0, dtype=torch.float64)
+        want[:, 1:] = ref.view(4, P, N) + pos.double().cpu()[1:]
+        assert _rel(out.view(4, P + 1, N), want) < 2e-6
+
+
+def test_gemm_rejects_bad_arguments():
+    from fitclip_amd._lib import FitclipHipError
+    a, w = torch.zeros(8, 48, device=DEV), torch.zeros(8, 48, device=DEV)
+    with pytest.raises(FitclipHipError, match="multiple of 32"):
+        ops.gemm(a, w, None, ops.EPI_STORE_F32)
+    with pytest.raises(FitclipHipError, match="bias"):
+        ops.gemm(torch.zeros(8, 64, device=DEV), torch.zeros(8, 64, device=DEV), None, ops.EPI_BIAS_T)
+
+
+@pytest.mark.parametrize("D", [128, 256, 512, 768])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(D, out_dtype):
+    x = _rand(333, D, seed=D) * 3 + 0.7
+    g, b = _rand(D, seed=1) * 0.1 + 1, _rand(D, seed=2) * 0.1
+    ref = O.layer_norm(x, g, b).double()
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), out_dtype)
+    assert _rel(y, ref) < (3e-6 if out_dtype == torch.float32 else 5e-3)
+    # strided rows (ln_post on the CLS rows) and gathered rows (ln_final on the EOT rows)
+    xs = x[:330].reshape(110, 3 * D)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), torch.float32, row_stride=3 * D, rows=110)
+    assert _rel(y, O.layer_norm(xs[:, :D], g, b)) < 3e-6
+    idx = torch.tensor([5, 0, 332, 17, 17], dtype=torch.int32)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), torch.float32, gather=idx.to(DEV))
+    assert _rel(y, ref[idx.long()]) < 3e-6
+
+
+def _attention_ref(qkv, n, S, heads, causal):
+    D = heads * 64
+    q, k, v = qkv.double().view(n, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + O.causal_mask(S).double()
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(n * S, D)
+
+
+@pytest.mark.parametrize("n,S,heads,causal", [(3, 197, 12, False), (5, 77, 8, True), (2, 17, 4, False),
+                                              (4, 16, 2, True), (1, 224, 1, False), (2, 33, 2, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention(n, S, heads, causal, dtype):
+    qkv = _rand(n * S, 3 * heads * 64, seed=S)
+    qkv[:, :heads * 64] *= 2.0  # sharper softmax
+    qd = qkv.to(DEV).to(dtype)
+    ref = _attention_ref(qd.cpu(), n, S, heads, causal)
+    out = ops.attention(qd, n, S, heads, causal)
+    assert out.dtype == dtype
+    assert _rel(out, ref) < (3e-6 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_similarity_ranks_and_losses():
+    t, v = _rand(50, 512, seed=1), _rand(70, 512, seed=2)
+    s = ops.similarity(t.to(DEV), v.to(DEV), alpha=1.0)
+    assert s.shape == (50, 70) and _rel(s, t.double() @ v.double().T) < 2e-6
+    s2 = ops.similarity(t.to(DEV), v[:49].to(DEV), alpha=2.5)  # column count not a multiple of 4
+    assert s2.shape == (50, 49) and _rel(s2, 2.5 * (t.double() @ v[:49].double().T)) < 2e-6
+    # ranks with ties: same known answers as the oracle test
+    m = torch.tensor([[9., 1., 2., 3., 4.], [5., 5., 5., 5., 5.], [1., 2., 0., 4., 3.], [7., 3., 7., 7., 1.],
+                      [0., 0., 0., 0., 1.]])
+    assert ops.ranks(m.to(DEV)).tolist() == [0, 1, 4, 2, 0]
+    big = _rand(300, 1000, seed=3)
+    big[:, ::7] = big[:, 3:4]  # plant ties
+    want = O.ranks_of_target(big[:, 100:], torch.arange(300) + 0)  # offset handled below
+    got = ops.ranks(big.to(DEV)[:, 100:], 0)
+    assert got.tolist() == want.tolist()
+    got = ops.ranks(big.to(DEV), 100)
+    assert got.tolist() == O.ranks_of_target(big, torch.arange(300) + 100).tolist()
+    for n, scale in ((8, 1.0), (64, 30.0), (301, 66.7)):
+        a, b = _rand(n, n, seed=n) * scale, _rand(n, n, seed=n + 1) * scale
+        assert abs(float(ops.nce_loss(a.to(DEV))) - float(O.nce_loss(a.double()))) < 1e-4 * max(1, scale)
+        kd, ref = float(ops.teacher_student_nce_loss(a.to(DEV), b.to(DEV))), float(O.teacher_student_nce_loss(a.double(), b.double()))
+        assert abs(kd - ref) < 2e-5 * max(1.0, abs(ref))
+
+
+def test_loss_matches_reference_fixture(golden_dir):
+    g = np.load(golden_dir / "loss_ref.npz")
+    for t in sorted({k.rsplit("_", 1)[0] for k in g.files}):
+        s, te = torch.from_numpy(g[f"{t}_scores"]).to(DEV), torch.from_numpy(g[f"{t}_teacher"]).to(DEV)
+        assert abs(float(ops.nce_loss(s)) - float(g[f"{t}_nce"])) < 1e-4 * max(1.0, abs(float(g[f"{t}_nce"])))
+        assert abs(float(ops.teacher_student_nce_loss(s, te)) - float(g[f"{t}_kd"])) < 1e-4 * max(1.0, abs(float(g[f"{t}_kd"])))
+
+
+def test_wise_is_bit_exact_against_reference_fixture(golden_dir):
+    g = np.load(golden_dir / "wise_ref.npz")
+    names = sorted(k[3:] for k in g.files if k.startswith("m1_"))
+    for w in (0.0, 0.4, 0.5, 1.0):
+        for n in names:
+            a, b = torch.from_numpy(g[f"m1_{n}"]).to(DEV), torch.from_numpy(g[f"m2_{n}"]).to(DEV)
+            assert np.array_equal(ops.wise_axpby(a, b, w).cpu().numpy(), g[f"w{w}_{n}"]), (w, n)
+    a, b = _rand(1_000_003, seed=1).to(DEV), _rand(1_000_003, seed=2).to(DEV)  # ragged tail
+    assert torch.equal(ops.wise_axpby(a, b, 0.4).cpu(), ((1 - 0.4) * a + 0.4 * b).cpu())
+
+
+def test_pool_and_normalize():
+    e = _rand(6 * 8, 512, seed=9) + 0.3
+    ref = (e / e.norm(dim=-1, keepdim=True)).view(6, 8, 512).mean(1)
+    assert _rel(ops.pool_normalize(e.to(DEV), 6, 8), ref) < 2e-6
+    assert _rel(ops.l2_normalize(e.to(DEV)), e / e.norm(dim=-1, keepdim=True)) < 2e-6
+    assert ops.pool_normalize(torch.zeros(0, 512, device=DEV), 0, 8).shape == (0, 512)
