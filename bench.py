@@ -39,6 +39,23 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 EPI_NAMES = {0: "bias", 1: "bias_quickgelu", 2: "bias_residual", 3: "patch_embed", 4: "store_f32"}
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: min(logical CPUs, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()
+            if quota != "max":
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def synth_video_on_device(n_clips: int, n_frames: int, res: int, seed: int, device) -> torch.Tensor:
     """Clip-specific low-frequency pattern + per-frame noise, clipped to the CLIP-normalised pixel range (the same
     recipe as fitclip_amd.synth.make_video, generated with the device RNG so 1.2 GB never cross PCIe)."""
@@ -60,7 +77,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--chunk-frames", type=int, default=0)
     ap.add_argument("--gemm-tile", type=int, default=0)
-    ap.add_argument("--cpu-sample-clips", type=int, default=8)
+    ap.add_argument("--cpu-sample-clips", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -164,7 +181,7 @@ def main() -> None:
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import clip_oracle as O
-        cores = os.cpu_count() or 1
+        cores = min(host_cores(), 64)
         torch.set_num_threads(cores)
         sd_t = O.to_torch(sd)
         k = min(args.cpu_sample_clips, n_local)

@@ -369,9 +369,11 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
   const fc_config& c = h->cfg;
   const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_k();
   const size_t per = per_item_bytes(h, 0);
-  int chunk = std::min<long>(std::min(n, default_chunk(h, 0)), (long)(ws_bytes / per));
-  // the carve aligns every buffer to 256 B; shrink until the exact layout fits
-  while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) --chunk;
+  int chunk = std::min(n, default_chunk(h, 0));
+  if (carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) {  // smaller workspace: as many items as fit
+    chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
+    while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) --chunk;
+  }
   if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_image: workspace too small (need >= %zu bytes)", per + 2048);
   const int kind = c.precision;
   for (int off = 0; off < n; off += chunk) {
@@ -402,8 +404,11 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
   const fc_config& c = h->cfg;
   const int tw = c.transformer_width, L = c.context_length;
   const size_t per = per_item_bytes(h, 1);
-  int chunk = std::min<long>(std::min(n, default_chunk(h, 1)), (long)(ws_bytes / per));
-  while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) --chunk;
+  int chunk = std::min(n, default_chunk(h, 1));
+  if (carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) {
+    chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
+    while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) --chunk;
+  }
   if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_text: workspace too small (need >= %zu bytes)", per + 2048);
   const int kind = c.precision;
   for (int off = 0; off < n; off += chunk) {

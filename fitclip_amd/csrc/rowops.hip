@@ -227,17 +227,22 @@ __global__ void __launch_bounds__(256) transpose_convert_kernel(const float* __r
 // then one add (no fma contraction), so the result is bit-identical to the reference expression.
 __global__ void __launch_bounds__(256) wise_kernel(const float* __restrict__ a, const float* __restrict__ b, float w1,
                                                    float w2, float* __restrict__ out, size_t n4, size_t n) {
+#pragma clang fp contract(off)  // hipcc contracts a*b+c into fma by default; torch evaluates mul, mul, add
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(a + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(b + i * 4);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(w1, x[e]), __fmul_rn(w2, y[e]));
+    for (int e = 0; e < 4; ++e) {
+      const float p1 = w1 * x[e], p2 = w2 * y[e];
+      o[e] = p1 + p2;
+    }
     *reinterpret_cast<f32x4*>(out + i * 4) = o;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t i = n4 * 4 + threadIdx.x;
-    out[i] = __fadd_rn(__fmul_rn(w1, a[i]), __fmul_rn(w2, b[i]));
+    const float p1 = w1 * a[i], p2 = w2 * b[i];
+    out[i] = p1 + p2;
   }
 }
 
