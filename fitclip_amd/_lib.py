@@ -59,6 +59,7 @@ SIGNATURES = {
     "fc_wise": (_i32, [_vp, _vp, _f64, _vp, _sz, _vp]),
     "fc_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fc_layernorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "fc_add_layernorm": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fc_attention": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "fc_convert": (_i32, [_vp, _vp, _i32, _sz, _vp]),
     "fc_profile_enable": (_i32, [_vp, _i32]),

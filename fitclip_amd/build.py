@@ -14,7 +14,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 REPO = CSRC.parent.parent
 LIB = CSRC / "libfitclip_hip.so"
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "rowops.hip", "score.hip"]
-HEADERS = [CSRC / "common.h", REPO / "include" / "fitclip_hip.h"]
+HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", REPO / "include" / "fitclip_hip.h"]
 ARCH = "gfx950"
 
 

@@ -207,18 +207,27 @@ Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols) {
   return s;
 }
 
+// The 12 pre-LN residual blocks.  Every projection GEMM writes its output ("delta", element type T) with a plain
+// store epilogue; the residual add x += delta is folded into the LayerNorm that follows it.  On return the last
+// c_proj delta is still pending in s.xn: the caller folds it into ln_post / ln_final.
 int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal,
                hipStream_t st) {
   const int M = n_seq * S;
   const int kind = h->cfg.precision;
+  bool first = true;
   for (const Block& b : t.blocks) {
-    FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
+    if (first) {
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
+      first = false;
+    } else {
+      FC_TRY(launch_add_layernorm(s.x, w, s.xn, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, 1, st));
+    }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, 0, st));
     FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
-    FC_TRY(gemm(h, EPI_RESID_F32, s.xn, b.out_w, b.out_b, s.x, nullptr, M, w, w, w, 0, st));
-    FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, st));
+    FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.out_w, b.out_b, s.big, nullptr, M, w, w, w, 0, st));
+    FC_TRY(launch_add_layernorm(s.x, w, s.big, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, 1, st));
     FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
-    FC_TRY(gemm(h, EPI_RESID_F32, s.big, b.proj_w, b.proj_b, s.x, nullptr, M, w, 4 * w, w, 0, st));
+    FC_TRY(gemm(h, EPI_BIAS_T, s.big, b.proj_w, b.proj_b, s.xn, nullptr, M, w, 4 * w, w, 0, st));
   }
   return FC_OK;
 }
@@ -387,8 +396,8 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     FC_TRY(launch_layernorm(s.x, vw, nullptr, h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias"), s.x, vw, 0,
                             cn * T, vw, st));
     FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, st));
-    FC_TRY(launch_layernorm(s.x, (long)T * vw, nullptr, h->w("visual.ln_post.weight"), h->w("visual.ln_post.bias"),
-                            s.clsn, vw, kind, cn, vw, st));
+    FC_TRY(launch_add_layernorm(s.x, (long)T * vw, s.xn, (long)T * vw, nullptr, h->w("visual.ln_post.weight"),
+                                h->w("visual.ln_post.bias"), s.clsn, vw, kind, cn, vw, 0, st));
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }
@@ -417,8 +426,8 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
     FC_TRY(launch_text_embed(ids + (size_t)off * L, h->w("token_embedding.weight"), h->w("positional_embedding"), s.x,
                              s.eot, cn, L, tw, c.vocab_size, st));
     FC_TRY(run_blocks(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, st));
-    FC_TRY(launch_layernorm(s.x, tw, s.eot, h->w("ln_final.weight"), h->w("ln_final.bias"), s.clsn, tw, kind, cn, tw,
-                            st));
+    FC_TRY(launch_add_layernorm(s.x, tw, s.xn, tw, s.eot, h->w("ln_final.weight"), h->w("ln_final.bias"), s.clsn, tw,
+                                kind, cn, tw, 0, st));
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->tproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, tw, c.embed_dim, 0, st));
   }
@@ -462,6 +471,11 @@ int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const void* W, c
 int fc_layernorm(const float* x, int64_t xs, const int32_t* gather, const float* g, const float* b, void* y,
                  int64_t ys, int32_t out_kind, int32_t rows, int32_t D, fc_stream st) {
   return launch_layernorm(x, (long)xs, gather, g, b, y, (long)ys, out_kind, rows, D, st);
+}
+int fc_add_layernorm(float* x, int64_t xs, const void* delta, int64_t ds, const int32_t* gather, const float* g,
+                     const float* b, void* y, int64_t ys, int32_t kind, int32_t rows, int32_t D, int32_t write_x,
+                     fc_stream st) {
+  return launch_add_layernorm(x, (long)xs, delta, (long)ds, gather, g, b, y, (long)ys, kind, rows, D, write_x, st);
 }
 int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream st) {

@@ -65,6 +65,10 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
 // out_kind: 0 = f32, 1 = bf16.
 int launch_layernorm(const float* x, long x_stride, const int* gather, const float* gamma, const float* beta,
                      void* y, long y_stride, int out_kind, int rows, int D, hipStream_t stream);
+// v = x[r] + delta[r] (delta of element kind `kind`, as y); x[r] = v if write_x; y[i] = LN(v).  r = gather ? gather[i] : i.
+int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
+                         const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
+                         int write_x, hipStream_t stream);
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream);
 int launch_cls_pos(float* x, const float* cls, const float* pos, int n, int tokens, int D, hipStream_t stream);
 int launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int* eot, int n, int L,

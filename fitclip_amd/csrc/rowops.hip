@@ -86,6 +86,101 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// Fused residual add + LayerNorm:  v = x[r] + delta[r];  (x[r] = v);  y[i] = LN(v).  `delta` is the projection output
+// a GEMM just wrote (element type T, as y), so the residual update costs no extra pass over the fp32 stream and the
+// GEMM epilogue stays a pure store (reference: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x)), slip.py:382-385).
+template <int D, typename T>
+__global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ x, long x_stride,
+                                                            const T* __restrict__ delta, long d_stride,
+                                                            const int* __restrict__ gather,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            long y_stride, int rows, int write_x) {
+  static_assert(D % 256 == 0 || D == 128, "width");
+  constexpr int V4 = D / 256, REM = (D % 256) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+    const long src = gather ? gather[row] : row;
+    float* xr = x + src * x_stride;
+    const T* dr = delta + src * d_stride;
+    f32x4 v[V4 > 0 ? V4 : 1];
+    float s[REM > 0 ? REM : 1];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      const int c = i * 256 + lane * 4;
+      v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+      if constexpr (sizeof(T) == 2) {
+        const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(dr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += static_cast<float>(d4[e]);
+      } else {
+        v[i] += *reinterpret_cast<const f32x4*>(dr + c);
+      }
+      if (write_x) *reinterpret_cast<f32x4*>(xr + c) = v[i];
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      const int c = V4 * 256 + i * 64 + lane;
+      s[i] = xr[c] + static_cast<float>(dr[c]);
+      if (write_x) xr[c] = s[i];
+      sum += s[i];
+    }
+    const float mean = wave_sum(sum) * (1.f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] -= mean;
+        sq += v[i][e] * v[i][e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      s[i] -= mean;
+      sq += s[i] * s[i];
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / D) + 1e-5f);
+    T* yr = y + (long)row * y_stride;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      const int c = i * 256 + lane * 4;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * g4[e] + b4[e];
+      put4<T>(yr + c, o);
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      const int c = V4 * 256 + i * 64 + lane;
+      put<T>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+    }
+  }
+}
+
+template <typename T>
+int add_layernorm_dispatch(float* x, long xs, const void* delta, long ds, const int* gather, const float* g,
+                           const float* b, void* y, long ys, int rows, int D, int write_x, hipStream_t st) {
+  const int blocks = min((rows + 3) / 4, kMaxBlocks);
+  const T* dl = reinterpret_cast<const T*>(delta);
+  T* yo = reinterpret_cast<T*>(y);
+  switch (D) {
+    case 128: hipLaunchKernelGGL((add_layernorm_kernel<128, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
+    case 256: hipLaunchKernelGGL((add_layernorm_kernel<256, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
+    case 512: hipLaunchKernelGGL((add_layernorm_kernel<512, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
+    case 768: hipLaunchKernelGGL((add_layernorm_kernel<768, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
+    case 1024: hipLaunchKernelGGL((add_layernorm_kernel<1024, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
+    default: return fail(FC_EINVAL, "add_layernorm: unsupported width %d", D);
+  }
+  FC_CHECK_LAUNCH("add_layernorm");
+  return FC_OK;
+}
+
 template <typename OutT>
 int layernorm_dispatch(const float* x, long xs, const int* gather, const float* g, const float* b, void* y, long ys,
                        int rows, int D, hipStream_t st) {
@@ -260,6 +355,20 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
     return fail(FC_EINVAL, "layernorm: operands must be 16-byte aligned");
   return out_kind == 1 ? layernorm_dispatch<bf16>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream)
                        : layernorm_dispatch<float>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
+}
+
+int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
+                         const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
+                         int write_x, hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  const int esz = kind == 1 ? 2 : 4;
+  if ((x_stride % 4) || (d_stride * esz) % 8 || (y_stride * esz) % 8 ||
+      (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta) & 15))
+    return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned");
+  return kind == 1 ? add_layernorm_dispatch<bf16>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows,
+                                                  D, write_x, stream)
+                   : add_layernorm_dispatch<float>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows,
+                                                   D, write_x, stream);
 }
 
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream) {

@@ -68,6 +68,19 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
     return y
 
 
+def add_layernorm(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                  write_x: bool = True) -> torch.Tensor:
+    """x += delta (in place, if write_x); returns LayerNorm(x + delta) in delta's dtype."""
+    _dev(x, "x", torch.float32), _dev(delta, "delta"), _dev(gamma, "gamma", torch.float32)
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=delta.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().fc_add_layernorm(x.data_ptr(), D, delta.data_ptr(), D, None, gamma.data_ptr(),
+                                                beta.data_ptr(), y.data_ptr(), D, _KIND[delta.dtype], rows, D,
+                                                int(write_x), _lib.current_stream()), "fc_add_layernorm")
+    return y
+
+
 def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False) -> torch.Tensor:
     """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]."""
     _dev(qkv, "qkv")

@@ -128,6 +128,12 @@ FC_API int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const voi
             int32_t P, int32_t tile, fc_stream stream);
 FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather, const float* gamma, const float* beta,
                  void* y, int64_t y_stride, int32_t out_kind, int32_t rows, int32_t D, fc_stream stream);
+/* v = x[r] + delta[r]; if write_x: x[r] = v; y[i] = LayerNorm(v) * gamma + beta, r = gather ? gather[i] : i.  The
+ * residual update of a pre-LN block (slip.py:382-385) folded into the LayerNorm that follows it.  delta and y have
+ * element kind `kind`. */
+FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64_t d_stride, const int32_t* gather,
+                     const float* gamma, const float* beta, void* y, int64_t y_stride, int32_t kind, int32_t rows,
+                     int32_t D, int32_t write_x, fc_stream stream);
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);

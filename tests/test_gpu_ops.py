@@ -23,7 +23,8 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-GEMM_SHAPES = [(300, 256, 256, 1), (1000, 512, 768, 2), (37, 128, 3072, 1), (515, 768, 128, 2), (16, 132, 64, 1)]
+GEMM_SHAPES = [(300, 256, 256, 1), (1000, 512, 768, 2), (37, 128, 3072, 1), (515, 768, 128, 2), (16, 132, 64, 1),
+               (5000, 768, 256, 3), (700, 264, 768, 3), (70000, 512, 192, 3)]
 
 
 @pytest.mark.parametrize("M,N,K,tile", GEMM_SHAPES)
@@ -40,6 +41,8 @@ def test_gemm_all_epilogues(M, N, K, tile, dtype):
     out = ops.gemm(ad, wd, bd, ops.EPI_GELU_T, tile=tile)
     z = ref + bias.double()
     assert _rel(out, z * torch.sigmoid(1.702 * z)) < tol
+    if tile == 3:  # the persistent / pipelined kernel only has the two store epilogues
+        return
     resid = _rand(M, N, seed=4)
     acc = resid.to(DEV).clone()
     ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=tile)
@@ -80,6 +83,23 @@ def test_layernorm(D, out_dtype):
     idx = torch.tensor([5, 0, 332, 17, 17], dtype=torch.int32)
     y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), torch.float32, gather=idx.to(DEV))
     assert _rel(y, ref[idx.long()]) < 3e-6
+
+
+@pytest.mark.parametrize("D", [128, 512, 768])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_add_layernorm(D, dtype):
+    x, d = _rand(257, D, seed=D) * 2 + 0.3, _rand(257, D, seed=D + 1)
+    g, b = _rand(D, seed=1) * 0.1 + 1, _rand(D, seed=2) * 0.1
+    dd = d.to(DEV).to(dtype)
+    want_x = x.double() + dd.double().cpu()
+    ref = O.layer_norm(want_x.float(), g, b).double()
+    xd = x.to(DEV).clone()
+    y = ops.add_layernorm(xd, dd, g.to(DEV), b.to(DEV))
+    assert y.dtype == dtype and _rel(xd, want_x) < 1e-6
+    assert _rel(y, ref) < (3e-6 if dtype == torch.float32 else 5e-3)
+    xd2 = x.to(DEV).clone()
+    y2 = ops.add_layernorm(xd2, dd, g.to(DEV), b.to(DEV), write_x=False)
+    assert torch.equal(xd2.cpu(), x) and torch.equal(y2, y)
 
 
 def _attention_ref(qkv, n, S, heads, causal):
