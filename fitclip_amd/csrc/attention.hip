@@ -19,6 +19,7 @@
 //
 // f32 kernel (parity path): plain VALU, one thread per query row, K/V broadcast from LDS, online softmax in fp32.
 #include "common.h"
+#include <cstdlib>
 
 namespace fc {
 
@@ -158,6 +159,166 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(const bf16* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 kernel, second generation (what the first profile asked for: the v1 kernel above spent its time in exposed
+// staging latency, 2-byte output stores and an unbalanced 13-tiles-over-4-waves split, not in MFMAs):
+//   * K and V both arrive by LDS-DMA (`global_load_lds_dwordx4`, no VGPR round trip, issued once per workgroup and
+//     overlapped with the Q fragment loads); both stay ROW-major [key][64 d] in LDS.  K uses the 16-byte chunk swizzle
+//     of the GEMM (conflict-free ds_read_b128 of the QK^T A-operand); V uses a 32-byte granule swizzle
+//     (granule ^ ((key >> 1) & 3)) that makes the transposing read below conflict-free.  The swizzles are applied to
+//     the per-lane SOURCE address (the DMA destination is lane-linear).
+//   * P.V is computed as O^T = V^T . P^T: the V^T A-operand (8 keys of one d per lane) is fetched with
+//     `ds_read_b64_tr_b16`, the hardware transposing LDS read (cdna_hip_programming.md T10): lane 4q+p of a 16-lane
+//     group supplies the address of key row q, d columns 4p..4p+3, and lane i receives column i of the four rows.
+//     The P^T B-operand is the exponentiated S^T accumulator itself (keys already on the k axis).  Queries stay on
+//     the lanes, so the softmax denominator is lane-local and each lane ends with 4 consecutive d of one query.
+//   * the 16x64 output tile is transposed through a private 2 KiB LDS patch and stored as 8 rows x 128 B per
+//     instruction; exp is a bare v_exp_f32 (scores pre-scaled by log2(e)/8).
+//   * NWAVES waves per workgroup, each owning q-tiles w, w + NWAVES, ... (7 waves for 13 visual q-tiles: 93 % balance).
+template <int NKT, int NWAVES, bool CAUSAL>
+__global__ void __launch_bounds__(NWAVES * 64) attn_bf16_v2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                  int S, int heads) {
+  constexpr int NK = NKT * 16;
+  constexpr int OFF_V = NK * 128;
+  constexpr int OFF_O = 2 * NK * 128;  // NWAVES x 2 KiB output patches
+  constexpr int MAXQ = 2;              // q-tiles per wave held in registers (Q fragments are preloaded)
+  static_assert(NKT % 2 == 0, "P.V consumes key tiles in pairs");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int D = heads * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)seq * S * ld + h * 64;
+  const bf16* Kg = base + D;
+  const bf16* Vg = base + 2 * D;
+
+  // ---- stage K and V by LDS-DMA: one wave-instruction = 8 key rows x 128 B
+  {
+    const int rin = lane >> 3, pc = lane & 7;
+    for (int grp = wave; grp < 2 * (NK / 8); grp += NWAVES) {
+      const bool isv = grp >= NK / 8;
+      const int row = (isv ? grp - NK / 8 : grp) * 8 + rin;
+      const int srow = min(row, S - 1);  // padded keys read a valid row; they are masked / multiplied by P = 0
+      const int c = isv ? ((((pc >> 1) ^ ((row >> 1) & 3)) << 1) | (pc & 1)) : (pc ^ ((row >> 1) & 7));
+      const bf16* src = (isv ? Vg : Kg) + (long)srow * ld + c * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + grp * 1024), 16, 0, 0);
+    }
+  }
+  const int r = lane & 15, q4 = lane >> 4, f = (r >> 1) & 7;
+  const int nqt = (S + 15) >> 4;
+  // ---- Q fragments of this wave's q-tiles (B-operand of S^T = K.Q^T: lane holds 8 d of query r)
+  bf16x8 qf[MAXQ][2];
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int qt = wave + i * NWAVES;
+    const int qrow = min(qt * 16 + r, S - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[i][s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * ld + (4 * s + q4) * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float kScale = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  char* patch = smem + OFF_O + wave * 2048;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int qt = wave + i * NWAVES;
+    if (qt >= nqt) break;
+    const int query = qt * 16 + r;
+    f32x4 sT[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (!CAUSAL || t <= qt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + (t * 16 + r) * 128 + (((4 * s + q4) ^ f) << 4));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][s], acc, 0, 0, 0);
+        }
+      }
+      sT[t] = acc;
+    }
+    // scale, mask (only tiles that can contain masked keys), max
+    float mx = kNegInf;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const bool partial = (t * 16 + 16 > S) || (CAUSAL && t >= qt);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = sT[t][e] * kScale;
+        if (partial) {
+          const int key = t * 16 + 4 * q4 + e;
+          if (key >= S || (CAUSAL && key > query)) v = kNegInf;
+        }
+        sT[t][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = __builtin_amdgcn_exp2f(sT[t][e] - mx);
+        sT[t][e] = p;
+        sum += p;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+
+    // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposing-read addresses: lane 4q+p of its 16-lane group -> key row (.. + q), d columns 16n + 4p .. +3
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < NKT / 2; ++ks) {
+      if (CAUSAL && 2 * ks > qt) continue;
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = static_cast<bf16>(sT[2 * ks][e]);
+        pf[4 + e] = static_cast<bf16>(sT[2 * ks + 1][e]);
+      }
+      const int key0 = ks * 32 + 4 * q4 + tq;   // rows of the first read (k-slots j = 0..3), +16 for the second
+      const int sw0 = (key0 >> 1) & 3, sw1 = ((key0 + 16) >> 1) & 3;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(smem + OFF_V + key0 * 128 + ((n ^ sw0) << 5) + tp * 8));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(smem + OFF_V + (key0 + 16) * 128 + ((n ^ sw1) << 5) + tp * 8));
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[n], 0, 0, 0);
+      }
+    }
+    // o[n][e] = O(query r, d = 16n + 4 q4 + e): pack, transpose through the wave's LDS patch, store full 128-B rows
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x4 pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = static_cast<bf16>(o[n][e] * inv);
+      *reinterpret_cast<bf16x4*>(patch + r * 128 + (((n * 4 + q4) ^ ((r & 7) << 1)) << 3)) = pk;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = hh * 8 + (lane >> 3), ch = lane & 7;
+      const bf16x8 val = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((2 * ch) ^ ((row & 7) << 1)) << 3));
+      const int qo = qt * 16 + row;
+      if (qo < S) *reinterpret_cast<bf16x8*>(out + ((long)seq * S + qo) * D + h * 64 + ch * 8) = val;
+    }
+  }
+}
+
 // f32 parity kernel: thread per query, K/V rows broadcast from LDS.
 template <bool CAUSAL>
 __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
@@ -226,6 +387,29 @@ __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__
   }
 }
 
+template <int NKT, int NWAVES>
+int launch_bf16_v2(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
+  constexpr int NK = NKT * 16;
+  constexpr int lds = 2 * NK * 128 + NWAVES * 2048;
+  if ((S + 15) / 16 > 2 * NWAVES) return fail(FC_EINVAL, "attention(bf16): %d query tiles exceed the wave plan", (S + 15) / 16);
+  static bool configured = false;
+  if (!configured && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)attn_bf16_v2_kernel<NKT, NWAVES, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bf16_v2_kernel<NKT, NWAVES, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail(FC_ELAUNCH, "attention(bf16): cannot raise dynamic LDS");
+    configured = true;
+  }
+  const dim3 grid(n_seq * heads), block(NWAVES * 64);
+  if (causal)
+    hipLaunchKernelGGL((attn_bf16_v2_kernel<NKT, NWAVES, true>), grid, block, lds, st, (const bf16*)qkv, (bf16*)out, S, heads);
+  else
+    hipLaunchKernelGGL((attn_bf16_v2_kernel<NKT, NWAVES, false>), grid, block, lds, st, (const bf16*)qkv, (bf16*)out, S, heads);
+  FC_CHECK_LAUNCH("attention(bf16 v2)");
+  return FC_OK;
+}
+
 template <int NKT>
 int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
   constexpr int NK = NKT * 16;
@@ -247,6 +431,13 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
   if (S <= 0 || heads <= 0) return fail(FC_EINVAL, "attention: S=%d heads=%d", S, heads);
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) return fail(FC_EINVAL, "attention: unaligned operand");
   if (precision == PREC_BF16) {
+    static const bool use_v1 = getenv("FITCLIP_ATTN_V1") != nullptr;  // A/B switch for the first-generation kernel
+    if (!use_v1) {
+      if (S <= 32) return launch_bf16_v2<2, 2>(qkv, out, n_seq, S, heads, causal, stream);
+      if (S <= 96) return launch_bf16_v2<6, 5>(qkv, out, n_seq, S, heads, causal, stream);
+      if (S <= 224) return launch_bf16_v2<14, 7>(qkv, out, n_seq, S, heads, causal, stream);
+      return fail(FC_EINVAL, "attention(bf16): sequence length %d > 224 not supported", S);
+    }
     if (S <= 32) return launch_bf16<2>(qkv, out, n_seq, S, heads, causal, stream);
     if (S <= 96) return launch_bf16<6>(qkv, out, n_seq, S, heads, causal, stream);
     if (S <= 224) return launch_bf16<14>(qkv, out, n_seq, S, heads, causal, stream);

@@ -34,7 +34,7 @@ def test_gemm_all_epilogues(M, N, K, tile, dtype):
     ad, wd = a.to(DEV).to(dtype), w.to(DEV).to(dtype)
     a64, w64 = ad.double().cpu(), wd.double().cpu()  # the operands the kernel actually sees
     ref = a64 @ w64.T
-    tol = 2e-6 if dtype == torch.float32 else 6e-3   # bf16: one output rounding (2^-9) on O(1) values
+    tol = 5e-6 if dtype == torch.float32 else 6e-3   # f32: summation-order noise over K <= 3072; bf16: one output rounding (2^-9)
     bd = bias.to(DEV)
     out = ops.gemm(ad, wd, bd, ops.EPI_BIAS_T, tile=tile)
     assert out.dtype == dtype and _rel(out, ref + bias.double()) < tol
