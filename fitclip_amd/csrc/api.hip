@@ -233,7 +233,7 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
 }
 
 int default_chunk(const fc_handle* h, int tower) {
-  if (tower == 0) return h->cfg.chunk_frames > 0 ? h->cfg.chunk_frames : 256;
+  if (tower == 0) return h->cfg.chunk_frames > 0 ? h->cfg.chunk_frames : 512;
   return h->cfg.chunk_texts > 0 ? h->cfg.chunk_texts : 1024;
 }
 
