@@ -143,17 +143,18 @@ def main() -> None:
     for r in records:
         if r["ms"] <= 0:
             continue
-        key = (r["epilogue"], r["N"], r["K"], r["M"])
+        key = (r["epilogue"], r["N"], r["K"], r["M"], r["tile"])
         agg = by_kernel[key]
         agg[0] += r["ms"]
         agg[1] += 1
         agg[2] += 2.0 * r["M"] * r["N"] * r["K"]
     gemm_ms = sum(v[0] for v in by_kernel.values())
     gemm_flops = sum(v[2] for v in by_kernel.values())
-    (epi, N, K, M), (ms, cnt, flops) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+    (epi, N, K, M, tile), (ms, cnt, flops) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+    kname = {1: "gemm_kernel<128x128>", 2: "gemm_kernel<256x256>", 3: "gemm_pipelined_kernel<256x256>"}.get(tile, "gemm")
     peak = PEAK_TFLOPS[args.precision]
     achieved = flops / (ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision},{EPI_NAMES[epi]}> M={M} N={N} K={K}",
+    roofline = {"bound": "mfma", "kernel": f"{kname}<{args.precision},{EPI_NAMES[epi]}> M={M} N={N} K={K}",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
                 "flops_per_launch": flops / cnt,

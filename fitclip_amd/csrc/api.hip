@@ -167,7 +167,7 @@ int gemm(fc_handle* h, int epi, const void* A, const void* W, const float* bias,
   GemmArgs a{};
   a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = aux; a.alpha = 1.f;
   a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = ldc; a.P = P;
-  ProfScope ps(h, st, h->cfg.precision, epi, h->cfg.gemm_tile, a);
+  ProfScope ps(h, st, h->cfg.precision, epi, gemm_resolved_tile(h->cfg.precision, epi, a, h->cfg.gemm_tile), a);
   return launch_gemm(h->cfg.precision, epi, a, h->cfg.gemm_tile, st);
 }
 

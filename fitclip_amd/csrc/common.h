@@ -54,6 +54,8 @@ struct GemmArgs {
 
 // tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)
 int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStream_t stream);
+// which kernel `tile` = 0 resolves to: 1 / 2 = one-tile-per-workgroup 128x128 / 256x256, 3 = persistent pipelined
+int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile);
 
 // ------------------------------------------------------------------------------------------- attention
 // qkv: T [n_seq * S, 3 * D] (q | k | v, heads of 64 inside each), out: T [n_seq * S, D]

@@ -63,15 +63,20 @@ bool pipelined_ok(const GemmArgs& a) {
          (size_t)a.N * a.ldw * esz < (1ull << 32);
 }
 
+template <typename T>
+int resolve_tile(int epi, const GemmArgs& a, int tile) {
+  if (tile != 0) return tile;
+  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T;
+  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
+  return t256 >= 512 ? 2 : 1;
+}
+
 // tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (BIAS_T / GELU_T only)
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T;
-  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (tile == 0) {
-    if (kHasPipelined && t256 >= 192 && pipelined_ok<T>(a)) tile = 3;
-    else tile = t256 >= 512 ? 2 : 1;
-  }
+  tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
     if constexpr (kHasPipelined) {
       if (!pipelined_ok<T>(a)) return fail(FC_EINVAL, "gemm: shape not supported by the pipelined kernel");
@@ -97,6 +102,10 @@ int launch_epi(int epi, const GemmArgs& a, int tile, hipStream_t stream) {
 }
 
 }  // namespace
+
+int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile) {
+  return precision == PREC_BF16 ? resolve_tile<bf16>(epilogue, a, tile) : resolve_tile<float>(epilogue, a, tile);
+}
 
 int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStream_t stream) {
   const int esz = precision == PREC_BF16 ? 2 : 4;
