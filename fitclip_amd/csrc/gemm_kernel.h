@@ -135,11 +135,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   const int b_base = BM * ROWB + (wn * TN + r) * ROWB;
 
   const int nk = g.K / BKE;
-  stage_load(0, 0);
+  // the two block-GEMM epilogues use the rotated K order of gemm_pipelined_kernel (bit-identical results); scoring
+  // (EPI_STORE_F32) and patch embedding keep the natural order, so a score does not depend on its column position
+  const int rot = (EPI == EPI_BIAS_T || EPI == EPI_GELU_T) ? (n0 >> 8) % nk : 0;
+  auto krot = [&](int kt) { return kt + rot >= nk ? kt + rot - nk : kt + rot; };
+  stage_load(0, krot(0));
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (ABL != 1 && kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
+    if (ABL != 1 && kt + 1 < nk) stage_load((kt + 1) & 1, krot(kt + 1));
     const char* st = smem + (kt & 1) * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -248,7 +252,7 @@ __device__ __forceinline__ void block_barrier() {
 // to their first use), and the hand-over to the next K-tile (wait for its DMA, barrier, issue the DMA two tiles ahead,
 // first fragment reads) sits in front of the LAST group of the current tile, so neither LDS latency nor the barrier
 // leaves the matrix pipe idle.  The accumulators start from the bias slice (no bias registers in the epilogue).
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0, int ROT = 1>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const GemmArgs g) {
   constexpr int NW = WM * WN;
   constexpr int BKE = ROWB / (int)sizeof(T);
@@ -290,9 +294,19 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   static_assert((NW * 4) % 8 == 0, "swizzle term must not depend on i");
   const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
   unsigned offA[LPA], offB[LPB];
+  const int nk = g.K / BKE;
+  // K-tiles of a tile are visited in the rotated order rot, rot+1, ..., nk-1, 0, ..., rot-1 with rot = (first column / 256) mod nk:
+  // the workgroups that share an activation panel then read different K-slices (different L2 channels) at any moment
+  // instead of hammering the same lines in lockstep (+5..12 % on the K = 768 shapes).  rot only depends on the
+  // N-tile, so a row's result still does not depend on the batch around it; gemm_kernel uses the same order.
+  int rot = 0;
   auto tile_sources = [&](int tile, int& m0, int& n0) {
-    m0 = (tile / tilesN) * BM;
-    n0 = (tile % tilesN) * BN;
+    const int tm = tile / tilesN, tn = tile % tilesN;
+    m0 = tm * BM;
+    n0 = tn * BN;
+    if constexpr (ROT == 1) rot = (n0 >> 8) % nk;  // a function of the output column block only
+    if constexpr (ROT == 2) rot = (tn + 5 * tm) % nk;
+    if constexpr (ROT == 3) rot = (2 * (tn % 3) + 7 * (tm % 5)) % nk;
 #pragma unroll
     for (int i = 0; i < LPA; ++i) {
       const int row = (wave + i * NW) * 8 + rin;
@@ -307,6 +321,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     }
   };
   auto stage_load = [&](int stage, int kt) {
+    kt += rot;
+    if (kt >= nk) kt -= nk;
     char* dst = smem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
@@ -331,7 +347,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
   const int a_base = (wm * TM + r) * ROWB;
   const int b_base = BM * ROWB + (wn * TN + r) * ROWB;
-  const int nk = g.K / BKE;
 
   if constexpr (ABL == 4) {  // lab experiment: de-phase the workgroups (quarter-tile steps) so their epilogues do not coincide
     const long long until = clock64() + (long long)(pos & 3) * (g.K / BKE) * 550;

@@ -210,3 +210,48 @@ def test_evaluate_driver_reproduces_config1_golden(golden_dir, capsys):
     for k in ("r1", "r5", "r10", "mr"):
         assert out[k] == pytest.approx(float(g[k])), (k, out)
     assert abs(out["loss/val"] - float(g["loss_val"])) < 2e-3
+
+
+@pytest.mark.parametrize("clips,frames,n_text", [(256, 8, 256), (1024, 16, 1024)])
+def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_text):
+    """BASELINE configs[1] (256 clips x 8 frames + 256 texts) and one rank's shard of configs[3] (1024 clips x 16
+    frames + 1024 texts) at FULL size, checked through the size-independent property that a row's embedding does not
+    depend on the rest of the batch: the big batch is built from 4 base clips / 8 base captions whose embeddings are
+    computed alone (and those small cases are pinned to the oracle by the golden tests above)."""
+    d = synth.VIT_B_16
+    enc = _encoder(vitb16_state_dict, "bf16")
+    base_v = torch.from_numpy(synth.make_video(4, frames, d, seed=21)).to(DEV)
+    base_t = torch.from_numpy(synth.make_text(8, d, seed=21)).to(DEV)
+    ref_v = enc.encode_video(base_v)
+    ref_t = enc.encode_text({"input_ids": base_t})
+    gen = torch.Generator().manual_seed(1)
+    pick_v = torch.randint(0, 4, (clips,), generator=gen)
+    pick_t = torch.randint(0, 8, (n_text,), generator=gen)
+    out_v = enc.encode_video(base_v[pick_v.to(DEV)])
+    out_t = enc.encode_text({"input_ids": base_t[pick_t.to(DEV)]})
+    assert torch.equal(out_v, ref_v[pick_v.to(DEV)])
+    assert torch.equal(out_t, ref_t[pick_t.to(DEV)])
+    # scoring at full size: T @ V^T equals the 8 x 4 block matrix it must be, and every rank is consistent with it
+    scores = ops.similarity(out_t, out_v)
+    small = ops.similarity(ref_t, ref_v)
+    assert torch.equal(scores, small[pick_t.to(DEV)][:, pick_v.to(DEV)])
+    n = min(clips, n_text)
+    ranks = ops.ranks(scores[:n, :n].contiguous())
+    want = O.ranks_of_target(scores[:n, :n].cpu(), torch.arange(n))
+    assert ranks.cpu().tolist() == want.tolist()
+
+
+def test_wise_full_size_is_bit_exact(vitb16_state_dict):
+    """WiSE over all 149.6 M parameters of ViT-B/16 (BASELINE configs[2]): bit-identical to the reference expression
+    `(1 - w) * p1 + w * p2` evaluated by torch on the CPU."""
+    d = synth.VIT_B_16
+    sd2 = synth.perturbed_state_dict(vitb16_state_dict, d, seed=9, rel=0.05)
+    e1, e2 = _encoder(vitb16_state_dict, "bf16"), _encoder(sd2, "bf16")
+    ens = wise(e1, e2, weight_for_2=0.5)
+    for k in ("model.visual.conv1.weight", "model.token_embedding.weight", "model.transformer.resblocks.11.mlp.c_fc.bias",
+              "model.visual.transformer.resblocks.0.attn.in_proj_weight", "model.ln_final.weight"):
+        name = k[len("model."):]
+        want = (1 - 0.5) * torch.from_numpy(vitb16_state_dict[name]) + 0.5 * torch.from_numpy(sd2[name])
+        assert torch.equal(dict(ens.named_parameters())[k].cpu(), want), k
+    video = torch.from_numpy(synth.make_video(2, 2, d, seed=3)).to(DEV)
+    assert torch.isfinite(ens.encode_video(video)).all()

@@ -81,23 +81,10 @@ void launch_plain(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, st, a);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL>
-void launch_persistent(const GemmArgs& a, hipStream_t st) {
-  constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 2048 : 0) + 2048;
-  auto kern = gemm_persistent_kernel<T, BM, BN, WM, WN, EPI, ABL>;
-  static bool configured = false;
-  if (!configured) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
-  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(WM * WN * 64), lds, st, a);
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL, int ROT = 0>
 void launch_pipelined(const GemmArgs& a, hipStream_t st) {
   constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 2048 : 0) + 2048;
-  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, ABL>;
+  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, ABL, ROT>;
   static bool configured = false;
   if (!configured) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

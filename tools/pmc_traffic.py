@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide prescribes) of
+`bench.py` into per-launch HBM traffic of the dominant kernel and writes profiles/traffic_<round>.json.
+
+gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+stream -> doubled; WRITE_SIZE is exact for 16-byte-per-lane stores; both are in KiB.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <grid> out.json
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_dispatch(path, counter, needle, grid):
+    vals = []
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and needle in r["Kernel_Name"] and (grid is None or int(r["Grid_Size"]) == grid):
+            vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+def main():
+    fetch_csv, write_csv, needle, grid, out = sys.argv[1:6]
+    grid = None if grid == "any" else int(grid)
+    f = per_dispatch(fetch_csv, "FETCH_SIZE", needle, grid)
+    w = per_dispatch(write_csv, "WRITE_SIZE", needle, grid)
+    assert f and w, (len(f), len(w))
+    fetch_b = 2.0 * 1024.0 * sum(f) / len(f)
+    write_b = 1024.0 * sum(w) / len(w)
+    res = {"kernel_substring": needle, "launches_fetch": len(f), "launches_write": len(w),
+           "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+           "hbm_bytes_per_launch": fetch_b + write_b,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950), KiB units"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
