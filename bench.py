@@ -79,6 +79,7 @@ def main() -> None:
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N > 1 on one GPU")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -87,11 +88,15 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from fitclip_amd import distributed as D
     from fitclip_amd import ops, synth
@@ -131,7 +136,8 @@ def main() -> None:
     for _ in range(args.steps):
         ev, et, all_ranks = step()
     fence()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                           device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)

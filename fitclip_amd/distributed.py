@@ -46,8 +46,14 @@ def all_gather_rows(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
     if local.shape[0] != biggest:
         padded = local.new_zeros((biggest, *local.shape[1:]))
         padded[:local.shape[0]] = local
-    gathered = local.new_empty((world_size * biggest, *local.shape[1:]))
-    dist.all_gather_into_tensor(gathered, padded.contiguous())
+    if local.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal of the multi-rank path: stage through the host
+        host = padded.contiguous().cpu()
+        host_out = host.new_empty((world_size * biggest, *local.shape[1:]))
+        dist.all_gather_into_tensor(host_out, host)
+        gathered = host_out.to(local.device)
+    else:
+        gathered = local.new_empty((world_size * biggest, *local.shape[1:]))
+        dist.all_gather_into_tensor(gathered, padded.contiguous())
     if all(c == biggest for c in counts):
         return gathered
     return torch.cat([gathered[r * biggest: r * biggest + c] for r, c in enumerate(counts)])
