@@ -165,6 +165,16 @@ def main() -> None:
                 "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
                 "flops_per_launch": flops / cnt,
                 "share_of_step_time": round(ms / (elapsed * 1e3), 4)}
+    # HBM bytes per launch of that kernel come from a separate rocprofv3 PMC pass (FETCH_SIZE / WRITE_SIZE cannot be
+    # read from inside the process): tools/pmc_traffic.py writes them next to the rocprof summaries in profiles/.
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_r01.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("shape") == [M, N, K] and t.get("precision") == args.precision and t.get("epilogue") == EPI_NAMES[epi]:
+            roofline["traffic"] = t["hbm_bytes_per_launch"]
+            roofline["traffic_note"] = (f"PMC pass: fetch {t['fetch_bytes_per_launch'] / 1e6:.0f} MB + write "
+                                        f"{t['write_bytes_per_launch'] / 1e6:.0f} MB per launch; algorithmic "
+                                        f"{(M * K + N * K + M * N) * (2 if args.precision == 'bf16' else 4) / 1e6:.0f} MB")
     step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
     all_gemms = {"achieved": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                  "frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak, 4),

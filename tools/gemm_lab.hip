@@ -91,7 +91,8 @@ void launch_pipelined(const GemmArgs& a, hipStream_t st) {
     configured = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(WM * WN * 64), lds, st, a);
+  const int cap = 256 * (BM * BN >= 256 * 256 ? 1 : 2);
+  hipLaunchKernelGGL(kern, dim3(tiles < cap ? tiles : cap), dim3(WM * WN * 64), lds, st, a);
 }
 
 #include "gemm_lab_variants.inc"
