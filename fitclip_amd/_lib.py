@@ -54,6 +54,8 @@ SIGNATURES = {
     "fc_l2_normalize": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fc_similarity": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
     "fc_ranks": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "fc_ranks_of": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "fc_group_mean": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "fc_nce_loss": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "fc_kd_loss": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "fc_wise": (_i32, [_vp, _vp, _f64, _vp, _sz, _vp]),

@@ -450,7 +450,15 @@ int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb, int32_
   return launch_gemm(PREC_F32, EPI_STORE_F32, a, 1, st);
 }
 int fc_ranks(const float* s, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t off, int32_t* ranks, fc_stream st) {
-  return launch_ranks(s, ld, n_rows, n_cols, off, ranks, st);
+  return launch_ranks(s, ld, n_rows, n_cols, off, nullptr, ranks, st);
+}
+int fc_ranks_of(const float* s, int32_t ld, int32_t n_rows, int32_t n_cols, const int32_t* targets, int32_t* ranks,
+                fc_stream st) {
+  if (!targets) return fail(FC_EINVAL, "fc_ranks_of: targets is null");
+  return launch_ranks(s, ld, n_rows, n_cols, 0, targets, ranks, st);
+}
+int fc_group_mean(const float* in, float* out, int32_t n_groups, int32_t group, int32_t dim, fc_stream st) {
+  return launch_group_mean(in, out, n_groups, group, dim, st);
 }
 int fc_nce_loss(const float* s, int32_t n, float* out, float* ws, fc_stream st) { return launch_nce_loss(s, n, out, ws, st); }
 int fc_kd_loss(const float* s, const float* t, int32_t n, float* out, float* ws, fc_stream st) {

@@ -77,13 +77,15 @@ int launch_text_embed(const int64_t* ids, const float* tok, const float* pos, fl
                       int D, int vocab, hipStream_t stream);
 int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int frames, int dim, hipStream_t stream);
 int launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t stream);
+int launch_group_mean(const float* in, float* out, int n_groups, int group, int dim, hipStream_t stream);
 int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream_t stream);
 int launch_transpose_convert(const float* in, void* out, int out_kind, int rows, int cols, hipStream_t stream);
 int launch_wise(const float* a, const float* b, double w, float* out, size_t n, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- score
-int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, int32_t* ranks,
-                 hipStream_t stream);
+// rank of column targets[i] (or i + target_offset when targets == nullptr) in the stable descending order of row i
+int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, const int32_t* targets,
+                 int32_t* ranks, hipStream_t stream);
 int launch_nce_loss(const float* scores, int n, float* out, float* ws, hipStream_t stream);
 int launch_kd_loss(const float* scores, const float* teacher, int n, float* out, float* ws, hipStream_t stream);
 

@@ -40,7 +40,7 @@ int num_cus() {
 template <typename T, int EPI>
 int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
-  constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 2048 : 0) + 2048;
+  constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 32 * (BN / WN) : 0) + 2048;
   auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI>;
   static bool configured = false;
   if (!configured) {

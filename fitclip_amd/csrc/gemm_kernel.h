@@ -262,10 +262,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int RG = (BM + BN) / 8;
   constexpr int LPW = RG / NW;
   constexpr bool kStaged = sizeof(T) == 2;            // bf16 outputs: LDS-transposed, 16-byte full-line stores
-  constexpr int OFF_STG = 2 * STAGE;                  // NW x 2 KiB
-  constexpr int OFF_BIAS = OFF_STG + (kStaged ? NW * 2048 : 0);  // 2 x 1 KiB
-  constexpr int NST = kStaged ? FM * 2 : FM * FN;     // store instructions per wave per interior tile
-  static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64), "tile");
+  constexpr int ROWP = TN * 2;                        // bytes per row of a wave's output patch (bf16)
+  constexpr int CPR = ROWP / 16;                      // 16-byte chunks per patch row
+  constexpr int PATCH = 16 * ROWP;                    // one 16-row pass of the wave tile
+  constexpr int RPI = 64 / CPR;                       // output rows per store instruction (8 x 128 B or 4 x 256 B)
+  constexpr int IPP = 16 / RPI;                       // store instructions per pass
+  constexpr int OFF_STG = 2 * STAGE;                  // NW patches
+  constexpr int OFF_BIAS = OFF_STG + (kStaged ? NW * PATCH : 0);  // 2 x 1 KiB
+  constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
+  static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T, "epilogue");
   static_assert(LPW + NST < 64, "vmcnt range");
   using FragT = typename Frag<T>::type;
@@ -305,8 +310,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     m0 = tm * BM;
     n0 = tn * BN;
     if constexpr (ROT == 1) rot = (n0 >> 8) % nk;  // a function of the output column block only
-    if constexpr (ROT == 2) rot = (tn + 5 * tm) % nk;
-    if constexpr (ROT == 3) rot = (2 * (tn % 3) + 7 * (tm % 5)) % nk;
 #pragma unroll
     for (int i = 0; i < LPA; ++i) {
       const int row = (wave + i * NW) * 8 + rin;
@@ -348,10 +351,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   const int a_base = (wm * TM + r) * ROWB;
   const int b_base = BM * ROWB + (wn * TN + r) * ROWB;
 
-  if constexpr (ABL == 4) {  // lab experiment: de-phase the workgroups (quarter-tile steps) so their epilogues do not coincide
-    const long long until = clock64() + (long long)(pos & 3) * (g.K / BKE) * 550;
-    while (clock64() < until) __builtin_amdgcn_s_sleep(32);
-  }
   int m0, n0;
   tile_sources(t, m0, n0);
   bias_load(0, n0);
@@ -462,9 +461,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
       prev_counted = false;
     } else {
       if constexpr (kStaged) {
-        char* stg = smem + OFF_STG + wave * 2048;
-        char* wr = stg + r * 128 + ((q & 1) << 3);
-        const int rrow = lane >> 3, rch = lane & 7;
+        char* stg = smem + OFF_STG + wave * PATCH;
+        char* wr = stg + r * ROWP + ((q & 1) << 3);
+        const int rrow = lane / CPR, rch = lane % CPR;
         T* cbase = reinterpret_cast<T*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * g.ldc + cn0 + wn * TN + rch * 8;
         const bool col_ok = cn0 + wn * TN + rch * 8 < g.N;
 #pragma unroll
@@ -479,19 +478,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
             bf16x4 o;
             o[0] = static_cast<bf16>(v[0]); o[1] = static_cast<bf16>(v[1]);
             o[2] = static_cast<bf16>(v[2]); o[3] = static_cast<bf16>(v[3]);
-            *reinterpret_cast<bf16x4*>(wr + (((j * 2 + (q >> 1)) ^ (r & 7)) << 4)) = o;
+            *reinterpret_cast<bf16x4*>(wr + (((j * 2 + (q >> 1)) ^ (r & (CPR - 1))) << 4)) = o;
           }
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int row = h * 8 + rrow;
-            const bf16x8 val = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
-            T* p = cbase + (size_t)(i * 16 + h * 8) * g.ldc;
+          for (int h = 0; h < IPP; ++h) {
+            const int row = h * RPI + rrow;
+            const bf16x8 val = *reinterpret_cast<const bf16x8*>(stg + row * ROWP + ((rch ^ (row & (CPR - 1))) << 4));
+            T* p = cbase + (size_t)(i * 16 + h * RPI) * g.ldc;
             if (interior || (cm0 + wm * TM + i * 16 + row < g.M && col_ok)) {
               // non-temporal: the tile is not read again by this kernel; a plain store write-allocates in L2 and evicts
               // the operand panels the other workgroups of the XCD are sharing (measured: operand re-fetch -35 %,
               // kernel +6..18 % on the N >= 2304 shapes)
-              if constexpr (ABL == 6) *reinterpret_cast<bf16x8*>(p) = val;
-              else __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(p));
+              __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(p));
             }
           }
         }

@@ -296,6 +296,18 @@ __global__ void __launch_bounds__(256) pool_normalize_kernel(const float* __rest
   }
 }
 
+// out[g] = mean over the `group` consecutive rows of group g (template averaging of the zero-shot label prompts,
+// video_text_classification.py:88-90).  Sequential fp32 sum then one division, as torch.mean over a short axis.
+__global__ void __launch_bounds__(256) group_mean_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int group, int dim) {
+  const int g = blockIdx.x;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < group; ++k) acc += in[((long)g * group + k) * dim + c];
+    out[(long)g * dim + c] = acc / (float)group;
+  }
+}
+
 template <typename OutT>
 __global__ void __launch_bounds__(256) convert_kernel(const float* __restrict__ in, OutT* __restrict__ out, size_t n4,
                                                       size_t n) {
@@ -404,6 +416,14 @@ int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int f
   if (frames <= 0 || dim <= 0 || dim > 1024) return fail(FC_EINVAL, "pool_normalize: frames=%d dim=%d", frames, dim);
   hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_clips), dim3(256), 0, stream, frame_emb, out, frames, dim);
   FC_CHECK_LAUNCH("pool_normalize");
+  return FC_OK;
+}
+
+int launch_group_mean(const float* in, float* out, int n_groups, int group, int dim, hipStream_t stream) {
+  if (n_groups <= 0) return FC_OK;
+  if (group <= 0 || dim <= 0) return fail(FC_EINVAL, "group_mean: group=%d dim=%d", group, dim);
+  hipLaunchKernelGGL(group_mean_kernel, dim3(n_groups), dim3(256), 0, stream, in, out, group, dim);
+  FC_CHECK_LAUNCH("group_mean");
   return FC_OK;
 }
 

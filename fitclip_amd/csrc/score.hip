@@ -26,10 +26,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // rank[i] = #{j : s[i,j] > s[i,t]} + #{j < t : s[i,j] == s[i,t]},  t = i + target_offset  (stable descending order)
 __global__ void __launch_bounds__(256) ranks_kernel(const float* __restrict__ s, int ld, int n_cols, int target_offset,
-                                                    int32_t* __restrict__ ranks) {
+                                                    const int32_t* __restrict__ targets, int32_t* __restrict__ ranks) {
   __shared__ int red[4];
   const int i = blockIdx.x;
-  const int t = i + target_offset;
+  int t = targets ? targets[i] : i + target_offset;
+  t = t < 0 ? 0 : (t >= n_cols ? n_cols - 1 : t);  // never read outside the row
   const float* row = s + (long)i * ld;
   const float ref = row[t];
   int cnt = 0;
@@ -109,12 +110,13 @@ __global__ void __launch_bounds__(256) finish_mean_kernel(const float* __restric
 
 }  // namespace
 
-int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, int32_t* ranks,
-                 hipStream_t stream) {
+int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, const int32_t* targets,
+                 int32_t* ranks, hipStream_t stream) {
   if (n_rows <= 0) return FC_OK;
-  if (target_offset < 0 || target_offset + n_rows > n_cols || ld < n_cols)
+  if (n_cols <= 0 || ld < n_cols || (!targets && (target_offset < 0 || target_offset + n_rows > n_cols)))
     return fail(FC_EINVAL, "ranks: rows=%d cols=%d offset=%d ld=%d", n_rows, n_cols, target_offset, ld);
-  hipLaunchKernelGGL(ranks_kernel, dim3(n_rows), dim3(256), 0, stream, scores, ld, n_cols, target_offset, ranks);
+  hipLaunchKernelGGL(ranks_kernel, dim3(n_rows), dim3(256), 0, stream, scores, ld, n_cols, target_offset, targets,
+                     ranks);
   FC_CHECK_LAUNCH("ranks");
   return FC_OK;
 }

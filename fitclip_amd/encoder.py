@@ -6,7 +6,7 @@ tokenizer / transform / frame-sampler factories and `should_pad_batch` have the 
 from __future__ import annotations
 
 import zlib
-from typing import Iterable, Iterator, Mapping
+from typing import Iterable, Iterator, Mapping, Optional
 
 import torch
 import torch.nn.functional as F
@@ -46,10 +46,11 @@ class HashTokenizer:
 
 
 class ClipVideoTextEncoder(VideoTextEncoder):
-    def __init__(self, model: CLIP, num_frames: int = 4) -> None:
+    def __init__(self, model: CLIP, num_frames: int = 4, bpe_path: Optional[str] = None) -> None:
         super().__init__()
         self.model = model
         self.num_frames = num_frames
+        self.bpe_path = bpe_path  # local bpe_simple_vocab_16e6.txt.gz; None -> HashTokenizer (framing only)
         self.mean, self.std = CLIP_MEAN, CLIP_STD
         # Same as the reference (:75-77): the CLIP temperature is unused, drop the parameter so it is not in
         # `named_parameters()` (WiSE) nor in the optimiser.
@@ -70,6 +71,9 @@ class ClipVideoTextEncoder(VideoTextEncoder):
         return ops.l2_normalize(self.model.encode_text(text["input_ids"]))
 
     def get_tokenizer(self) -> TYPE_TOKENIZER:
+        if self.bpe_path:
+            from .bpe import ClipBpeTokenizer
+            return ClipBpeTokenizer(self.bpe_path, self.model.context_length)
         return HashTokenizer(self.model.context_length, self.model.vocab_size)
 
     def decode_text(self, text: TYPE_TEXT_INPUT) -> Iterator[str]:
@@ -98,7 +102,7 @@ class ClipVideoTextEncoder(VideoTextEncoder):
             h, w = v.shape[-2:]
             scale = size / min(h, w)
             nh, nw = max(size, round(h * scale)), max(size, round(w * scale))
-            v = F.interpolate(v, size=(nh, nw), mode="bicubic", align_corners=False, antialias=True)
+            v = F.interpolate(v, size=(nh, nw), mode="bicubic", align_corners=False)  # torchvision Resize on tensors: no antialias
             top, left = (nh - size) // 2, (nw - size) // 2
             return self._normalize(v[..., top:top + size, left:left + size])
 

@@ -155,6 +155,35 @@ def ranks(scores: torch.Tensor, target_offset: int = 0) -> torch.Tensor:
     return out
 
 
+def ranks_of(scores: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """Position of column targets[i] in the stable descending order of row i (zero-shot classification metrics)."""
+    if scores.device.type != "cuda" or scores.dtype != torch.float32 or scores.stride(1) != 1:
+        raise _lib.FitclipHipError("scores must be a float32 ROCm tensor with unit column stride")
+    targets = _dev(targets.to(device=scores.device, dtype=torch.int32).contiguous(), "targets", torch.int32)
+    n_rows, n_cols = scores.shape
+    if targets.numel() != n_rows:
+        raise ValueError("one target per row")
+    out = torch.empty((n_rows,), dtype=torch.int32, device=scores.device)
+    if n_rows:
+        with torch.cuda.device(scores.device):
+            _lib.check(_lib.load().fc_ranks_of(scores.data_ptr(), scores.stride(0), n_rows, n_cols, targets.data_ptr(),
+                                               out.data_ptr(), _lib.current_stream()), "fc_ranks_of")
+    return out
+
+
+def group_mean(x: torch.Tensor, group: int) -> torch.Tensor:
+    """[n * group, dim] -> [n, dim]: mean over each run of `group` consecutive rows."""
+    _dev(x, "x", torch.float32)
+    if group <= 0 or x.shape[0] % group:
+        raise ValueError("row count must be a multiple of the group size")
+    out = torch.empty((x.shape[0] // group, x.shape[1]), dtype=torch.float32, device=x.device)
+    if out.shape[0]:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fc_group_mean(x.data_ptr(), out.data_ptr(), out.shape[0], group, x.shape[1],
+                                                 _lib.current_stream()), "fc_group_mean")
+    return out
+
+
 def _square(scores: torch.Tensor, name: str) -> torch.Tensor:
     scores = _dev(scores.contiguous(), name, torch.float32)
     if scores.dim() != 2 or scores.shape[0] != scores.shape[1]:

@@ -115,6 +115,12 @@ FC_API int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb,
                   int32_t ldo, fc_stream stream);
 FC_API int fc_ranks(const float* scores, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t target_offset, int32_t* ranks,
              fc_stream stream);
+/* Zero-shot classification (aligner/video_text_classification.py): fc_ranks_of = rank of the label
+ * column targets[i] in row i (Accuracy@k = rank < k, MedianRank); fc_group_mean = mean over the `group` template
+ * prompts of each label (:88-90), out [n_groups, dim]. */
+FC_API int fc_ranks_of(const float* scores, int32_t ld, int32_t n_rows, int32_t n_cols, const int32_t* targets,
+                int32_t* ranks, fc_stream stream);
+FC_API int fc_group_mean(const float* in, float* out, int32_t n_groups, int32_t group, int32_t dim, fc_stream stream);
 FC_API int fc_nce_loss(const float* scores, int32_t n, float* out, float* ws, fc_stream stream);
 FC_API int fc_kd_loss(const float* scores, const float* teacher_scores, int32_t n, float* out, float* ws, fc_stream stream);
 

@@ -191,6 +191,19 @@ def retrieval_metrics(scores: torch.Tensor) -> Dict[str, float]:
     return out
 
 
+def zero_shot_label_embeddings(encoded_prompts: torch.Tensor, template_count: int) -> torch.Tensor:
+    """video_text_classification.py:88-90: mean of the prompt embeddings over the templates of each label."""
+    return encoded_prompts.reshape(-1, template_count, encoded_prompts.shape[1]).mean(dim=1)
+
+
+def zero_shot_metrics(scores: torch.Tensor, label_id: torch.Tensor) -> Dict[str, float]:
+    """video_text_classification.py:62-63,110-118: Accuracy@1 / @5 (label among the k best columns) and the median
+    rank (+1) of the true label."""
+    ranks = ranks_of_target(scores, label_id)
+    return {"a1": (ranks < 1).float().mean().item(), "a5": (ranks < 5).float().mean().item(),
+            "mr": float(ranks.median().item() + 1)}
+
+
 def flatten_gathered(t: torch.Tensor) -> torch.Tensor:
     """tensor_utils.py:58-60: [world, B, ...] -> [world * B, ...]."""
     return t.view(-1, *t.shape[2:])

@@ -273,6 +273,67 @@ def golden_wise_encoder(report) -> None:
     report["wise_encoder_tiny"] = "oracle outputs stored"
 
 
+def _learn_toy_merges(words, n_merges):
+    """A small BPE trainer (ours) so that the merges file is synthetic data, not a copy of the published vocabulary."""
+    from collections import Counter
+    from fitclip_amd.bpe import byte_alphabet
+    alpha = byte_alphabet()
+    vocab = Counter()
+    for w in words:
+        chars = [alpha[b] for b in w.encode("utf-8")]
+        vocab[tuple(chars[:-1] + [chars[-1] + "</w>"])] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = Counter()
+        for sym, c in vocab.items():
+            for a, b in zip(sym, sym[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda pr: pairs[pr])
+        merges.append(best)
+        merged_vocab = Counter()
+        for sym, c in vocab.items():
+            out, i = [], 0
+            while i < len(sym):
+                if i + 1 < len(sym) and (sym[i], sym[i + 1]) == best:
+                    out.append(sym[i] + sym[i + 1])
+                    i += 2
+                else:
+                    out.append(sym[i])
+                    i += 1
+            merged_vocab[tuple(out)] += c
+        vocab = merged_vocab
+    return merges
+
+
+def golden_bpe(ref_slip, report) -> None:
+    """Pins fitclip_amd.bpe against the reference's own `SimpleTokenizer` class on a synthetic merges file."""
+    import gzip
+    from fitclip_amd.bpe import ClipBpeTokenizer, byte_alphabet
+    assert dict(enumerate(byte_alphabet())) == ref_slip.bytes_to_unicode()
+    corpus = ("a video of a person playing guitar in the kitchen while the dog is running on the beach people dancing "
+              "cooking food slowly quickly cats dogs birds swimming pool water blue sky playing played player "
+              "guitarist kitchens a photo of someone doing something outdoors indoors riding horse bicycle").split()
+    merges = _learn_toy_merges(corpus, 160)
+    path = HERE / "bpe_toy_merges.txt.gz"
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("#version: toy synthetic merges for tests\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    ref_tok = ref_slip.SimpleTokenizer(bpe_path=str(path))
+    mine = ClipBpeTokenizer(str(path), context_length=16)
+    texts = ["A video of a person playing guitar!", "the dog's running... on the BEACH &amp; pool",
+             "cooking   food\tslowly 123 times", "na\u00efve caf\u00e9 \u2014 \u00fcn\u00efc\u00f6d\u00e9 \u2603", "x" * 40,
+             "<|startoftext|> hi <|endoftext|>", "", "I'm they've it'll"]
+    expected = [ref_tok.encode(t) for t in texts]
+    for t, e in zip(texts, expected):
+        assert mine.encode(t) == e, t
+        assert mine.decode(e) == ref_tok.decode(e), t
+    (HERE / "bpe_toy.json").write_text(json.dumps({"texts": texts, "ids": expected,
+                                                   "decoded": [ref_tok.decode(e) for e in expected],
+                                                   "vocab_size": len(ref_tok.encoder)}, indent=1) + "\n")
+    report["bpe_vs_reference_slip.SimpleTokenizer"] = f"identical ids on {len(texts)} texts (toy merges, vocab {len(ref_tok.encoder)})"
+
+
 def main() -> None:
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -283,6 +344,7 @@ def main() -> None:
     golden_towers(ref_slip, report)
     golden_evaluate(report)
     golden_wise_encoder(report)
+    golden_bpe(ref_slip, report)
     (HERE / "PINNING.json").write_text(json.dumps(report, indent=2) + "\n")
     print(json.dumps(report, indent=2))
 

@@ -255,3 +255,31 @@ def test_wise_full_size_is_bit_exact(vitb16_state_dict):
         assert torch.equal(dict(ens.named_parameters())[k].cpu(), want), k
     video = torch.from_numpy(synth.make_video(2, 2, d, seed=3)).to(DEV)
     assert torch.isfinite(ens.encode_video(video)).all()
+
+
+def test_zero_shot_classification_matches_oracle(tiny_state_dict):
+    """labels x templates -> prompt embeddings -> template mean -> video @ labels^T -> Acc@1/5, MedR
+    (aligner/video_text_classification.py:29-140), HIP path vs oracle on the same seeded model and clips."""
+    from fitclip_amd.classification import VideoTextClassificationModule
+    d = synth.TINY
+    labels = ["cat", "dog", "guitar", "beach", "kitchen", "horse", "bicycle"]
+    templates = ["a video of a {}", "a clip showing a {}", "{} in the wild"]
+    enc = _encoder(tiny_state_dict, "fp32")
+    module = VideoTextClassificationModule(enc, labels, templates)
+    video = torch.from_numpy(synth.make_video(20, 2, d, seed=4))
+    label_id = torch.arange(20) % len(labels)
+    for s in range(0, 20, 8):
+        module.validation_step({"video": video[s:s + 8].to(DEV), "target": (None, label_id[s:s + 8])})
+    got = module.validation_epoch_end()
+    sd = O.to_torch(tiny_state_dict)
+    prompts = [t.format(l) for l in labels for t in templates]
+    ids = enc.get_tokenizer()(prompts)["input_ids"]
+    with torch.inference_mode():
+        lab = O.zero_shot_label_embeddings(O.encode_text(sd, {"input_ids": ids}), len(templates))
+        scores = O.encode_video(sd, video) @ lab.T
+    ref = O.zero_shot_metrics(scores, label_id)
+    assert np.abs(module.encoded_labels.cpu().numpy() - lab.numpy()).max() < F32_TOL
+    assert np.abs(module(video[:4].to(DEV)).cpu().numpy() - scores[:4].numpy()).max() < 5e-5
+    assert got == pytest.approx(ref)
+    pred = module.predict_step({"video": video[:4].to(DEV), "target": (None, label_id[:4]), "video_id": list("abcd")})
+    assert pred["predictions"].tolist() == scores[:4].argmax(-1).tolist()

@@ -173,3 +173,13 @@ def test_pool_and_normalize():
     assert _rel(ops.pool_normalize(e.to(DEV), 6, 8), ref) < 2e-6
     assert _rel(ops.l2_normalize(e.to(DEV)), e / e.norm(dim=-1, keepdim=True)) < 2e-6
     assert ops.pool_normalize(torch.zeros(0, 512, device=DEV), 0, 8).shape == (0, 512)
+
+
+def test_ranks_of_and_group_mean():
+    s = _rand(200, 37, seed=5)
+    s[:, ::5] = s[:, 2:3]  # ties
+    tgt = torch.randint(0, 37, (200,), generator=torch.Generator().manual_seed(0))
+    assert ops.ranks_of(s.to(DEV), tgt).cpu().tolist() == O.ranks_of_target(s, tgt).tolist()
+    x = _rand(7 * 5, 128, seed=6)
+    assert torch.equal(ops.group_mean(x.to(DEV), 5).cpu(), O.zero_shot_label_embeddings(x, 5))
+    assert torch.equal(ops.group_mean(x.to(DEV), 1).cpu(), x)

@@ -120,3 +120,30 @@ def test_synth_is_deterministic_and_sliceable():
     assert (t.max(axis=1) == eot).all() and (t[:, 0] == eot - 1).all()
     assert len(synth.parameter_shapes(synth.VIT_B_16)) == 301
     assert sum(int(np.prod(s)) for s in synth.parameter_shapes(synth.VIT_B_16).values()) == 149_620_736
+
+
+def test_bpe_tokenizer_matches_reference_fixture(golden_dir):
+    """fitclip_amd.bpe vs ids produced by the reference's own SimpleTokenizer on the synthetic merges file."""
+    from fitclip_amd.bpe import ClipBpeTokenizer
+    g = json.loads((golden_dir / "bpe_toy.json").read_text())
+    tok = ClipBpeTokenizer(str(golden_dir / "bpe_toy_merges.txt.gz"), context_length=16)
+    assert tok.vocab_size == g["vocab_size"]
+    for text, ids, dec in zip(g["texts"], g["ids"], g["decoded"]):
+        assert tok.encode(text) == ids, text
+        assert tok.decode(ids) == dec
+    out = tok(g["texts"])["input_ids"]
+    sot, eot = tok.token_id["<|startoftext|>"], tok.token_id["<|endoftext|>"]
+    assert out.shape == (len(g["texts"]), 16) and (out[:, 0] == sot).all()
+    long_row = out[4]  # 40 x's: truncated, EOT restored in the last slot (clip.tokenize(truncate=True))
+    assert int(long_row[-1]) == eot and int(long_row.max()) == eot
+    empty = out[6]
+    assert empty[:3].tolist() == [sot, eot, 0]
+
+
+def test_zero_shot_oracle_semantics():
+    prompts = torch.tensor([[1., 0.], [0., 1.], [1., 1.], [3., 1.]])
+    labels = O.zero_shot_label_embeddings(prompts, 2)
+    assert torch.equal(labels, torch.tensor([[0.5, 0.5], [2., 1.]]))
+    scores = torch.tensor([[0.9, 0.1, 0.3], [0.2, 0.2, 0.8]])
+    m = O.zero_shot_metrics(scores, torch.tensor([0, 1]))
+    assert m["a1"] == 0.5 and m["a5"] == 1.0 and m["mr"] == 1.0

@@ -83,7 +83,7 @@ void launch_plain(const GemmArgs& a, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL, int ROT = 0>
 void launch_pipelined(const GemmArgs& a, hipStream_t st) {
-  constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 2048 : 0) + 2048;
+  constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 32 * (BN / WN) : 0) + 2048;
   auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, ABL, ROT>;
   static bool configured = false;
   if (!configured) {
