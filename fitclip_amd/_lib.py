@@ -50,6 +50,7 @@ SIGNATURES = {
     "fc_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "fc_encode_image": (_i32, [_vp, _vp, _i32, _vp, _vp, _sz, _vp]),
     "fc_encode_text": (_i32, [_vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "fc_preprocess_u8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _vp]),
     "fc_pool_normalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "fc_l2_normalize": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fc_similarity": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),

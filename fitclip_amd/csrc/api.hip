@@ -434,6 +434,11 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
   return FC_OK;
 }
 
+int fc_preprocess_u8(const uint8_t* frames, float* out, int32_t n, int32_t H, int32_t W, int32_t R, const float* mean3,
+                     const float* std3, fc_stream st) {
+  if (!frames || !out || !mean3 || !std3) return fail(FC_EINVAL, "fc_preprocess_u8: null argument");
+  return launch_preprocess_u8(frames, out, n, H, W, R, mean3, std3, st);
+}
 int fc_pool_normalize(const float* e, float* out, int32_t n_clips, int32_t frames, int32_t dim, fc_stream st) {
   return launch_pool_normalize(e, out, n_clips, frames, dim, st);
 }

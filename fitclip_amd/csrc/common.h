@@ -72,6 +72,9 @@ int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stri
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
                          int write_x, hipStream_t stream);
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream);
+// uint8 [n,H,W,3] -> f32 NCHW [n,3,R,R]: /255, bicubic resize (shorter side R), centre crop, mean/std (host arrays)
+int launch_preprocess_u8(const unsigned char* frames, float* out, int n, int H, int W, int R, const float* mean3,
+                         const float* std3, hipStream_t stream);
 int launch_cls_pos(float* x, const float* cls, const float* pos, int n, int tokens, int D, hipStream_t stream);
 int launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int* eot, int n, int L,
                       int D, int vocab, hipStream_t stream);

@@ -2,6 +2,7 @@
 // All are one-wave-per-row or flat grid-stride kernels with 16-byte accesses (guide: Appendix B, Guideline 13).
 #include "common.h"
 #include <climits>
+#include <cmath>
 
 namespace fc {
 
@@ -219,6 +220,57 @@ __global__ void __launch_bounds__(256) im2col_kernel(const float* __restrict__ f
   }
 }
 
+// ---------------------------------------------------------------------------------- eval preprocessing (N1)
+// uint8 frames [n, H, W, 3] -> fp32 NCHW [n, 3, R, R]: /255, bicubic resize of the shorter side to R (PyTorch
+// semantics: A = -0.75, half-pixel centres, border taps clamped), centre crop, (x - mean) / std.  One thread per output
+// pixel, all three channels (the reference does this on the CPU per sample: clip_video_text_encoder.py:125-133).
+__device__ __forceinline__ void cubic_weights(float t, float w[4]) {
+  const float A = -0.75f;
+  const float t1 = t + 1.f, t2 = 1.f - t, t3 = 2.f - t;
+  w[0] = ((A * t1 - 5.f * A) * t1 + 8.f * A) * t1 - 4.f * A;
+  w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  w[2] = ((A + 2.f) * t2 - (A + 3.f)) * t2 * t2 + 1.f;
+  w[3] = ((A * t3 - 5.f * A) * t3 + 8.f * A) * t3 - 4.f * A;
+}
+
+__global__ void __launch_bounds__(256) preprocess_u8_kernel(const unsigned char* __restrict__ in,
+                                                            float* __restrict__ out, int n, int H, int W, int nh,
+                                                            int nw, int R, int top, int left, float3 mean,
+                                                            float3 inv_std) {
+  const float sy = (float)H / (float)nh, sx = (float)W / (float)nw;
+  const long total = (long)n * R * R;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % R), y = (int)((i / R) % R);
+    const long img = i / ((long)R * R);
+    const float ry = sy * ((float)(y + top) + 0.5f) - 0.5f, rx = sx * ((float)(x + left) + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    float wy[4], wx[4];
+    cubic_weights(ry - (float)iy, wy);
+    cubic_weights(rx - (float)ix, wx);
+    float acc[3] = {0.f, 0.f, 0.f};
+    const unsigned char* base = in + img * (long)H * W * 3;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(iy - 1 + a, 0), H - 1);
+      float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max(ix - 1 + b, 0), W - 1);
+        const unsigned char* p = base + ((long)yy * W + xx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[c] += wx[b] * ((float)p[c] / 255.f);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wy[a] * row[c];
+    }
+    const long plane = (long)R * R;
+    float* o = out + img * 3 * plane + (long)y * R + x;
+    o[0] = (acc[0] - mean.x) * inv_std.x;
+    o[plane] = (acc[1] - mean.y) * inv_std.y;
+    o[2 * plane] = (acc[2] - mean.z) * inv_std.z;
+  }
+}
+
 __global__ void __launch_bounds__(256) cls_pos_kernel(float* __restrict__ x, const float* __restrict__ cls,
                                                       const float* __restrict__ pos, int n, int tokens, int D) {
   const long total = (long)n * D;
@@ -392,6 +444,21 @@ int launch_im2col(const float* frames, void* patches, int out_kind, int n, int r
   else
     hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, stream, frames, (float*)patches, n, res, patch);
   FC_CHECK_LAUNCH("im2col");
+  return FC_OK;
+}
+
+int launch_preprocess_u8(const unsigned char* frames, float* out, int n, int H, int W, int R, const float* mean3,
+                         const float* std3, hipStream_t stream) {
+  if (n <= 0) return FC_OK;
+  if (H <= 0 || W <= 0 || R <= 0) return fail(FC_EINVAL, "preprocess: %dx%d -> %d", H, W, R);
+  // torchvision Resize(int): shorter side = R, longer side = int(R * long / short); then CenterCrop(R)
+  const int nh = H <= W ? R : (int)((long)R * H / W), nw = H <= W ? (int)((long)R * W / H) : R;
+  const int top = (int)lroundf((nh - R) / 2.f), left = (int)lroundf((nw - R) / 2.f);
+  const float3 mean = make_float3(mean3[0], mean3[1], mean3[2]);
+  const float3 inv = make_float3(1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(flat_blocks((size_t)n * R * R)), dim3(256), 0, stream, frames, out, n,
+                     H, W, nh, nw, R, top, left, mean, inv);
+  FC_CHECK_LAUNCH("preprocess_u8");
   return FC_OK;
 }
 

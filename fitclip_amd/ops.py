@@ -103,6 +103,22 @@ def to_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def preprocess_u8(frames: torch.Tensor, size: int, mean, std) -> torch.Tensor:
+    """uint8 [n, H, W, 3] on the device -> float32 [n, 3, size, size]: the CLIP eval transform (/255, bicubic resize of
+    the shorter side, centre crop, mean/std) in one kernel."""
+    _dev(frames, "frames", torch.uint8)
+    if frames.dim() != 4 or frames.shape[-1] != 3:
+        raise ValueError("expected uint8 frames [n, H, W, 3]")
+    n, H, W, _ = frames.shape
+    out = torch.empty((n, 3, size, size), dtype=torch.float32, device=frames.device)
+    m3, s3 = (_lib._f32 * 3)(*mean), (_lib._f32 * 3)(*std)
+    if n:
+        with torch.cuda.device(frames.device):
+            _lib.check(_lib.load().fc_preprocess_u8(frames.data_ptr(), out.data_ptr(), n, H, W, size, m3, s3,
+                                                    _lib.current_stream()), "fc_preprocess_u8")
+    return out
+
+
 def pool_normalize(frame_emb: torch.Tensor, n_clips: int, frames: int) -> torch.Tensor:
     """mean over frames of the L2-normalised frame embeddings (clip_video_text_encoder.py:85-89)."""
     _dev(frame_emb, "frame_emb", torch.float32)

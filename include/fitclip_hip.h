@@ -98,6 +98,12 @@ FC_API int fc_encode_image(fc_handle* h, const float* frames, int32_t n_frames, 
 FC_API int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n_texts, float* out, void* workspace,
                    size_t workspace_bytes, fc_stream stream);
 
+/* Eval transform on the device (clip_video_text_encoder.py:125-133): frames dev uint8 [n, H, W, 3]
+ * -> out dev f32 [n, 3, R, R] = normalise(center_crop(bicubic_resize(frames / 255, shorter side R), R)).  mean3 / std3
+ * are HOST arrays of 3 floats. */
+FC_API int fc_preprocess_u8(const uint8_t* frames, float* out, int32_t n, int32_t H, int32_t W, int32_t R,
+                     const float* mean3, const float* std3, fc_stream stream);
+
 /* clip_video_text_encoder.py:85-89: out[b] = mean_f(e[b,f] / ||e[b,f]||), NOT re-normalised.  e [n_clips*frames, dim] */
 FC_API int fc_pool_normalize(const float* frame_emb, float* out, int32_t n_clips, int32_t frames, int32_t dim,
                       fc_stream stream);

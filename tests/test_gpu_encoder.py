@@ -283,3 +283,26 @@ def test_zero_shot_classification_matches_oracle(tiny_state_dict):
     assert got == pytest.approx(ref)
     pred = module.predict_step({"video": video[:4].to(DEV), "target": (None, label_id[:4]), "video_id": list("abcd")})
     assert pred["predictions"].tolist() == scores[:4].argmax(-1).tolist()
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (240, 320), (360, 202), (256, 256)])
+def test_device_preprocessing_matches_the_eval_transform(tiny_state_dict, H, W):
+    """fc_preprocess_u8 vs the plugin's own eval transform (torch on the CPU: BHWC->BCHW, /255, bicubic
+    resize of the shorter side, centre crop, CLIP mean/std - clip_video_text_encoder.py:125-133)."""
+    enc = _encoder(tiny_state_dict, "fp32")  # the transform does not depend on the weights
+    enc.model.visual.input_resolution = 224
+    frames = torch.randint(0, 256, (3, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(H * W))
+    want = enc.get_eval_transform(torch.float32)(frames)
+    got = ops.preprocess_u8(frames.to(DEV), 224, enc.mean, enc.std).cpu()
+    assert got.shape == want.shape == (3, 3, 224, 224)
+    assert (got - want).abs().max() < 5e-5
+
+
+def test_encode_video_uint8_path(tiny_state_dict):
+    enc = _encoder(tiny_state_dict, "fp32")
+    frames = torch.randint(0, 256, (2, 3, 80, 96, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    tf = enc.get_eval_transform(torch.float32)
+    video = torch.stack([tf(v) for v in frames])  # what the reference's dataset would hand over
+    ref = enc.encode_video(video.to(DEV))
+    got = enc.encode_video_uint8(frames.to(DEV))
+    assert (got - ref).abs().max() < 2e-5
