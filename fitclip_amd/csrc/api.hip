@@ -4,6 +4,7 @@
 #include "common.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <vector>

@@ -50,6 +50,8 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldw, ldc;  // in elements
   int P;              // EPI_PATCH_F32: patches per image
+  int nblock;         // pipelined kernel: N-tiles per L2-resident weight block (0 = all)
+  int nsplit;         // pipelined kernel: XCD groups that split the N range (1, 2 or 4; 0 = 1)
 };
 
 // tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)

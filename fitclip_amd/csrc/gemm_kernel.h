@@ -280,14 +280,33 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- tile schedule: XCD x (= blockIdx & 7) owns a contiguous range of tiles, its workgroups stride through it
+  // ---- tile schedule.  XCD x (= blockIdx & 7) owns a contiguous range of M-panels; its workgroups stride through the
+  // tiles of that range in N-BLOCK-major order: for each block of `nblock` N-tiles, every M-panel of the range
+  // (nblock = 0: the whole N range, i.e. plain N-fastest order).  Tuning knobs, measured in profiles/r01_lab9/11:
+  // smaller blocks / an N-split over XCD groups change the L2 re-fetch volume by up to -20 % but not the in-situ time
+  // (the 4.7 MB c_fc weight and the ~6 live activation panels never fit a 4 MiB L2 together), so both default to off.
   const int tilesN = (g.N + BN - 1) / BN;
-  const int ntiles = ((g.M + BM - 1) / BM) * tilesN;
+  const int tilesM = (g.M + BM - 1) / BM;
   const int G = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
   const int nblk = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
-  const int tq = ntiles >> 3, tr = ntiles & 7;
-  const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+  // N-split: the 8 XCDs form `ngrp` groups; a group only ever touches its own 1/ngrp of the N range, so only that part
+  // of W competes for its L2s (c_fc: 2 x 2.4 MB instead of 4.7 MB per 4 MiB L2); the activation panels are then read
+  // by ngrp XCDs instead of one.
+  const int ngrp = (g.nsplit > 1 && 8 % g.nsplit == 0 && tilesN % g.nsplit == 0 && G == 8 * (G >> 3)) ? g.nsplit : 1;
+  const int grp = xcd % ngrp, xi = xcd / ngrp, nx = 8 / ngrp;
+  const int pq = tilesM / nx, pr = tilesM % nx;
+  const int mp0 = xi < pr ? xi * (pq + 1) : pr * (pq + 1) + (xi - pr) * pq;  // first M-panel of this XCD
+  const int npanel = pq + (xi < pr ? 1 : 0);
+  const int tnn = tilesN / ngrp, tn0 = grp * tnn;                          // N-tile range of this XCD's group
+  const int nbw = (g.nblock > 0 && g.nblock < tnn) ? g.nblock : tnn;
+  const int t_begin = 0, t_end = npanel * tnn;  // local tile index inside the XCD's range
+  auto tile_coords = [&](int k, int& tm, int& tn) {
+    const int per_block = npanel * nbw;
+    const int nb = k / per_block, rem = k - nb * per_block;
+    const int wb = min(nbw, tnn - nb * nbw);
+    tm = mp0 + rem / wb;
+    tn = tn0 + nb * nbw + rem % wb;
+  };
   int t = t_begin + pos;
   if (t >= t_end) return;
 
@@ -306,7 +325,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // N-tile, so a row's result still does not depend on the batch around it; gemm_kernel uses the same order.
   int rot = 0;
   auto tile_sources = [&](int tile, int& m0, int& n0) {
-    const int tm = tile / tilesN, tn = tile % tilesN;
+    int tm, tn;
+    tile_coords(tile, tm, tn);
     m0 = tm * BM;
     n0 = tn * BN;
     if constexpr (ROT == 1) rot = (n0 >> 8) % nk;  // a function of the output column block only

@@ -67,6 +67,10 @@ struct Variant {
   const char* name;
   std::function<void(const GemmArgs&, hipStream_t)> launch;
 };
+template <int NBLOCK, int NSPLIT = 0, typename F>
+std::function<void(const GemmArgs&, hipStream_t)> with_nblock(F f) {
+  return [f](const GemmArgs& a, hipStream_t st) { GemmArgs b = a; b.nblock = NBLOCK; b.nsplit = NSPLIT; f(b, st); };
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL>
 void launch_plain(const GemmArgs& a, hipStream_t st) {
@@ -107,6 +111,8 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
+  bf16* flush = nullptr;
+  if (argc > 3 && atoi(argv[3])) HIP_OK(hipMalloc(&flush, (size_t)640 << 20));
   std::vector<Variant> variants = make_variants();
   for (const Shape& sh : shapes) {
     bf16 *A, *W, *C;
@@ -133,13 +139,26 @@ int main(int argc, char** argv) {
       float worst = 0.f;
       for (float e : herr) worst = fmaxf(worst, e);
       for (int i = 0; i < 3; ++i) v.launch(a, st);
-      HIP_OK(hipEventRecord(e0, st));
-      for (int i = 0; i < reps; ++i) v.launch(a, st);
-      HIP_OK(hipEventRecord(e1, st));
-      HIP_OK(hipStreamSynchronize(st));
       float ms = 0.f;
-      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-      ms /= reps;
+      if (!flush) {
+        HIP_OK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) v.launch(a, st);
+        HIP_OK(hipEventRecord(e1, st));
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+      } else {  // cold caches: 640 MB are written between launches (evicts L2 and the 256 MiB Infinity Cache)
+        for (int i = 0; i < reps; ++i) {
+          fill_kernel<<<2048, 256, 0, st>>>(flush, (size_t)320 << 20, 7u + i, 1.0f);
+          HIP_OK(hipEventRecord(e0, st));
+          v.launch(a, st);
+          HIP_OK(hipEventRecord(e1, st));
+          HIP_OK(hipStreamSynchronize(st));
+          float one = 0.f;
+          HIP_OK(hipEventElapsedTime(&one, e0, e1));
+          ms += one / reps;
+        }
+      }
       const double tf = 2.0 * M * sh.N * sh.K / (ms * 1e-3) / 1e12;
       printf("%-9s M=%d N=%d K=%d  %-28s %8.3f ms %8.1f TF/s  %.3f of peak  maxrelerr=%.2e %s\n", sh.name, M, sh.N,
              sh.K, v.name, ms, tf, tf / 2500.0, worst, worst < 2e-2f ? "ok" : "WRONG(expected for ablations)");
