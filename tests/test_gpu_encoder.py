@@ -306,3 +306,25 @@ def test_encode_video_uint8_path(tiny_state_dict):
     ref = enc.encode_video(video.to(DEV))
     got = enc.encode_video_uint8(frames.to(DEV))
     assert (got - ref).abs().max() < 2e-5
+
+
+def test_small_workspace_means_more_passes_not_different_results(tiny_state_dict):
+    """fc_encode_image / fc_encode_text accept any workspace that holds at least one item: fewer bytes -> more chunks,
+    identical output; too few bytes -> FC_ENOMEM with a message, nothing launched."""
+    from fitclip_amd import _lib
+    d = synth.TINY
+    model = build_clip(tiny_state_dict, precision="bf16", device=DEV)
+    images = torch.from_numpy(synth.make_video(9, 1, d, seed=8)).reshape(9, 3, 64, 64).to(DEV)
+    ref = model.encode_image(images)
+    rt, lib = model._ensure_ready(), _lib.load()
+    need = lib.fc_workspace_bytes(rt.handle, 0, 9)
+    for frac in (0.5, 0.2):
+        ws = torch.empty(int(need * frac), dtype=torch.uint8, device=DEV)
+        out = torch.empty_like(ref)
+        _lib.check(lib.fc_encode_image(rt.handle, images.data_ptr(), 9, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _lib.current_stream()))
+        assert torch.equal(out, ref), frac
+    tiny_ws = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = lib.fc_encode_image(rt.handle, images.data_ptr(), 9, ref.data_ptr(), tiny_ws.data_ptr(), tiny_ws.numel(),
+                             _lib.current_stream())
+    assert rc == -3 and b"workspace too small" in lib.fc_last_error()
