@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .clip_model import CLIP
-from .frame_sampler import FrameSampler, RandomFromUniformIntervalsFrameSampler, UniformFrameSampler
+from .samplers import FrameSampler, RandomFromUniformIntervalsFrameSampler, UniformFrameSampler
 from .plugin_api import (TYPE_TEXT_INPUT, TYPE_TOKENIZER, TYPE_TRANSFORM, TYPE_VIDEO_INPUT, VideoTextEncoder,
                          float_standard_denormalize)
 

@@ -13,7 +13,7 @@ from typing import Callable, Iterable, Iterator, Mapping, Optional, Tuple
 import torch
 from torch import nn
 
-from .frame_sampler import FrameSampler
+from .samplers import FrameSampler
 
 TYPE_VIDEO_INPUT = torch.Tensor
 TYPE_TRANSFORM = Callable[[torch.Tensor], torch.Tensor]
