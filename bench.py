@@ -79,6 +79,8 @@ def main() -> None:
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prune-last-block", action="store_true",
+                    help="opt-in: only the pooled rows go through the MLP of the last block (identical embeddings)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N > 1 on one GPU")
     args = ap.parse_args()
 
@@ -106,7 +108,8 @@ def main() -> None:
     dims = synth.VIT_B_16
     sd = synth.make_state_dict(dims, seed=42)
     enc = ClipVideoTextEncoder(build_clip(sd, precision=args.precision, device=device,
-                                          chunk_frames=args.chunk_frames, gemm_tile=args.gemm_tile),
+                                          chunk_frames=args.chunk_frames, gemm_tile=args.gemm_tile,
+                                          prune_last_block=args.prune_last_block),
                                num_frames=args.frames)
     n_local, n_total = args.clips, args.clips * world
     video = synth_video_on_device(n_local, args.frames, dims.image_resolution, seed=1000 + rank, device=device)
@@ -190,7 +193,7 @@ def main() -> None:
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"CLIP ViT-B/16 dual encoder, {n_local} clips x {args.frames} frames x 224^2 + {n_local} "
                                f"x 77-token texts per GPU -> T@V^T -> ranks (BASELINE configs[1])",
-                   "clips_per_gpu": n_local, "frames": args.frames, "weights": "random init (seed 42)",
+                   "clips_per_gpu": n_local, "frames": args.frames, "weights": "random init (seed 42)", "prune_last_block": bool(args.prune_last_block),
                    "sharding": f"clips over {world} rank(s), one RCCL all-gather of embeddings"},
         "roofline": roofline, "roofline_all_gemms": all_gemms, "roofline_whole_path": whole_path,
         "retrieval": metrics,

@@ -68,13 +68,14 @@ class _Runtime:
 
 class CLIP(nn.Module):
     def __init__(self, dims: ClipDims = VIT_B_16, precision: str = "bf16", chunk_frames: int = 0,
-                 chunk_texts: int = 0, gemm_tile: int = 0) -> None:
+                 chunk_texts: int = 0, gemm_tile: int = 0, prune_last_block: bool = False) -> None:
         super().__init__()
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.dims = dims
         self.precision = precision
         self.chunk_frames, self.chunk_texts, self.gemm_tile = chunk_frames, chunk_texts, gemm_tile
+        self.prune_last_block = bool(prune_last_block)
         for name, shape in parameter_shapes(dims).items():
             *path, leaf = name.split(".")
             node: nn.Module = self
@@ -111,14 +112,14 @@ class CLIP(nn.Module):
             raise _lib.FitclipHipError(
                 f"CLIP parameters are on {dev}; move the model to the ROCm device first (no CPU fallback).")
         lib, rt = _lib.load(), self._rt
-        key = (self.precision, self.chunk_frames, self.chunk_texts, self.gemm_tile, dev.index)
+        key = (self.precision, self.chunk_frames, self.chunk_texts, self.gemm_tile, self.prune_last_block, dev.index)
         if rt.handle is None or rt.key != key:
             rt.close()
             d = self.dims
             cfg = _lib.fc_config(d.embed_dim, d.image_resolution, d.vision_layers, d.vision_width, d.vision_patch_size,
                                  d.context_length, d.vocab_size, d.transformer_width, d.transformer_heads,
                                  d.transformer_layers, _PRECISIONS[self.precision], self.chunk_frames,
-                                 self.chunk_texts, self.gemm_tile)
+                                 self.chunk_texts, self.gemm_tile, int(self.prune_last_block))
             h = _lib._vp()
             _lib.check(lib.fc_create(cfg, h), "fc_create")
             rt.handle, rt.key = h, key

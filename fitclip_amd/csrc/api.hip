@@ -208,29 +208,50 @@ Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols) {
   return s;
 }
 
-// The 12 pre-LN residual blocks.  Every projection GEMM writes its output ("delta", element type T) with a plain
-// store epilogue; the residual add x += delta is folded into the LayerNorm that follows it.  On return the last
-// c_proj delta is still pending in s.xn: the caller folds it into ln_post / ln_final.
+// The 12 pre-LN residual blocks followed by the final LayerNorm of the pooled rows (CLS rows: pool_idx == nullptr,
+// row i * pool_step; EOT rows: pool_idx).  Every projection GEMM writes its output ("delta", element type T) with a
+// plain store epilogue; the residual add x += delta is folded into the LayerNorm that follows it.
+//
+// cfg.prune_last_block: the towers only read the pooled row of each sequence after the last block, so in the last block
+// everything after the attention (out_proj, LayerNorm 2, c_fc, c_proj: 72 % of a block's FLOPs) is only computed for
+// those rows.  Rows of a GEMM / LayerNorm are independent, so the pooled rows come out bit-identical.
 int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal,
-               hipStream_t st) {
+               const float* fin_w, const float* fin_b, const int* pool_idx, long pool_step, hipStream_t st) {
   const int M = n_seq * S;
   const int kind = h->cfg.precision;
-  bool first = true;
-  for (const Block& b : t.blocks) {
-    if (first) {
+  const int esz = h->esz;
+  const size_t nl = t.blocks.size();
+  const long xs_pool = pool_idx ? w : pool_step * w;  // x row stride seen through the pooling index
+  for (size_t l = 0; l < nl; ++l) {
+    const Block& b = t.blocks[l];
+    if (l == 0) {
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
-      first = false;
     } else {
-      FC_TRY(launch_add_layernorm(s.x, w, s.xn, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, 1, st));
+      FC_TRY(launch_add_layernorm(s.x, w, s.xn, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, 1, 0, st));
     }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, 0, st));
     FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
+    if (l + 1 == nl && h->cfg.prune_last_block) {
+      const size_t blk = align_up((size_t)n_seq * w * esz);
+      char* ao = s.big;           // [n, w]  pooled rows of the attention output
+      char* d1 = s.big + blk;     // [n, w]  out_proj delta
+      char* xc = s.big + 2 * blk; // [n, w]  LayerNorm 2 output
+      char* d2 = s.big + 3 * blk; // [n, w]  c_proj delta
+      char* hc = s.big + 4 * blk; // [n, 4w] MLP hidden
+      FC_TRY(launch_gather_rows(s.xn, pool_idx, pool_step, ao, n_seq, w * esz, st));
+      FC_TRY(gemm(h, EPI_BIAS_T, ao, b.out_w, b.out_b, d1, nullptr, n_seq, w, w, w, 0, st));
+      FC_TRY(launch_add_layernorm(s.x, xs_pool, d1, w, pool_idx, b.ln2_w, b.ln2_b, xc, w, kind, n_seq, w, 1, 1, st));
+      FC_TRY(gemm(h, EPI_GELU_T, xc, b.fc_w, b.fc_b, hc, nullptr, n_seq, 4 * w, w, 4 * w, 0, st));
+      FC_TRY(gemm(h, EPI_BIAS_T, hc, b.proj_w, b.proj_b, d2, nullptr, n_seq, w, 4 * w, w, 0, st));
+      return launch_add_layernorm(s.x, xs_pool, d2, w, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 1, st);
+    }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.out_w, b.out_b, s.big, nullptr, M, w, w, w, 0, st));
-    FC_TRY(launch_add_layernorm(s.x, w, s.big, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, 1, st));
+    FC_TRY(launch_add_layernorm(s.x, w, s.big, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, 1, 0, st));
     FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
     FC_TRY(gemm(h, EPI_BIAS_T, s.big, b.proj_w, b.proj_b, s.xn, nullptr, M, w, 4 * w, w, 0, st));
   }
-  return FC_OK;
+  // the last c_proj delta is still pending in s.xn: fold it into the final LayerNorm of the pooled rows
+  return launch_add_layernorm(s.x, xs_pool, s.xn, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 0, st);
 }
 
 int default_chunk(const fc_handle* h, int tower) {
@@ -396,9 +417,8 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     FC_TRY(launch_cls_pos(s.x, h->w("visual.class_embedding"), h->w("visual.positional_embedding"), cn, T, vw, st));
     FC_TRY(launch_layernorm(s.x, vw, nullptr, h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias"), s.x, vw, 0,
                             cn * T, vw, st));
-    FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, st));
-    FC_TRY(launch_add_layernorm(s.x, (long)T * vw, s.xn, (long)T * vw, nullptr, h->w("visual.ln_post.weight"),
-                                h->w("visual.ln_post.bias"), s.clsn, vw, kind, cn, vw, 0, st));
+    FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),
+                      h->w("visual.ln_post.bias"), nullptr, T, st));
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }
@@ -420,15 +440,13 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
     while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) --chunk;
   }
   if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_text: workspace too small (need >= %zu bytes)", per + 2048);
-  const int kind = c.precision;
   for (int off = 0; off < n; off += chunk) {
     const int cn = std::min(chunk, n - off);
     const Scratch s = carve(static_cast<char*>(ws), cn, L, tw, h->esz, 0);
     FC_TRY(launch_text_embed(ids + (size_t)off * L, h->w("token_embedding.weight"), h->w("positional_embedding"), s.x,
                              s.eot, cn, L, tw, c.vocab_size, st));
-    FC_TRY(run_blocks(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, st));
-    FC_TRY(launch_add_layernorm(s.x, tw, s.xn, tw, s.eot, h->w("ln_final.weight"), h->w("ln_final.bias"), s.clsn, tw,
-                                kind, cn, tw, 0, st));
+    FC_TRY(run_blocks(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, h->w("ln_final.weight"),
+                      h->w("ln_final.bias"), s.eot, 0, st));
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->tproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, tw, c.embed_dim, 0, st));
   }
@@ -489,7 +507,7 @@ int fc_layernorm(const float* x, int64_t xs, const int32_t* gather, const float*
 int fc_add_layernorm(float* x, int64_t xs, const void* delta, int64_t ds, const int32_t* gather, const float* g,
                      const float* b, void* y, int64_t ys, int32_t kind, int32_t rows, int32_t D, int32_t write_x,
                      fc_stream st) {
-  return launch_add_layernorm(x, (long)xs, delta, (long)ds, gather, g, b, y, (long)ys, kind, rows, D, write_x, st);
+  return launch_add_layernorm(x, (long)xs, delta, (long)ds, gather, g, b, y, (long)ys, kind, rows, D, write_x, 0, st);
 }
 int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream st) {

@@ -69,10 +69,13 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
 // out_kind: 0 = f32, 1 = bf16.
 int launch_layernorm(const float* x, long x_stride, const int* gather, const float* gamma, const float* beta,
                      void* y, long y_stride, int out_kind, int rows, int D, hipStream_t stream);
-// v = x[r] + delta[r] (delta of element kind `kind`, as y); x[r] = v if write_x; y[i] = LN(v).  r = gather ? gather[i] : i.
+// v = x[r] + delta[d] (delta of element kind `kind`, as y); x[r] = v if write_x; y[i] = LN(v).  r = gather ? gather[i] : i;
+// d = delta_compact ? i : r.
 int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
-                         int write_x, hipStream_t stream);
+                         int write_x, int delta_compact, hipStream_t stream);
+// dst[i] = src row (idx ? idx[i] : i * step), rows of row_bytes bytes (multiple of 16)
+int launch_gather_rows(const void* src, const int* idx, long step, void* dst, int n, int row_bytes, hipStream_t stream);
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream);
 // uint8 [n,H,W,3] -> f32 NCHW [n,3,R,R]: /255, bicubic resize (shorter side R), centre crop, mean/std (host arrays)
 int launch_preprocess_u8(const unsigned char* frames, float* out, int n, int H, int W, int R, const float* mean3,

@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
                                                             const int* __restrict__ gather,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
-                                                            long y_stride, int rows, int write_x) {
+                                                            long y_stride, int rows, int write_x,
+                                                            int delta_compact) {
   static_assert(D % 256 == 0 || D == 128, "width");
   constexpr int V4 = D / 256, REM = (D % 256) / 64;
   const int lane = threadIdx.x & 63;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
   for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
     const long src = gather ? gather[row] : row;
     float* xr = x + src * x_stride;
-    const T* dr = delta + src * d_stride;
+    const T* dr = delta + (delta_compact ? (long)row : src) * d_stride;
     f32x4 v[V4 > 0 ? V4 : 1];
     float s[REM > 0 ? REM : 1];
     float sum = 0.f;
@@ -166,16 +167,17 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
 
 template <typename T>
 int add_layernorm_dispatch(float* x, long xs, const void* delta, long ds, const int* gather, const float* g,
-                           const float* b, void* y, long ys, int rows, int D, int write_x, hipStream_t st) {
+                           const float* b, void* y, long ys, int rows, int D, int write_x, int delta_compact,
+                           hipStream_t st) {
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   const T* dl = reinterpret_cast<const T*>(delta);
   T* yo = reinterpret_cast<T*>(y);
   switch (D) {
-    case 128: hipLaunchKernelGGL((add_layernorm_kernel<128, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
-    case 256: hipLaunchKernelGGL((add_layernorm_kernel<256, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
-    case 512: hipLaunchKernelGGL((add_layernorm_kernel<512, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
-    case 768: hipLaunchKernelGGL((add_layernorm_kernel<768, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
-    case 1024: hipLaunchKernelGGL((add_layernorm_kernel<1024, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x); break;
+    case 128: hipLaunchKernelGGL((add_layernorm_kernel<128, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
+    case 256: hipLaunchKernelGGL((add_layernorm_kernel<256, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
+    case 512: hipLaunchKernelGGL((add_layernorm_kernel<512, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
+    case 768: hipLaunchKernelGGL((add_layernorm_kernel<768, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
+    case 1024: hipLaunchKernelGGL((add_layernorm_kernel<1024, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
     default: return fail(FC_EINVAL, "add_layernorm: unsupported width %d", D);
   }
   FC_CHECK_LAUNCH("add_layernorm");
@@ -348,6 +350,20 @@ __global__ void __launch_bounds__(256) pool_normalize_kernel(const float* __rest
   }
 }
 
+// dst[i] = src[row(i)] for rows of `bytes` bytes (multiple of 16), row(i) = idx ? idx[i] : i * step.  Compacts the pooled
+// token rows (CLS / EOT) in front of the row-pruned last block.
+__global__ void __launch_bounds__(256) gather_rows_kernel(const char* __restrict__ src, const int* __restrict__ idx,
+                                                          long step, char* __restrict__ dst, int n, int bytes) {
+  const int per_row = bytes >> 4;
+  const long total = (long)n * per_row;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / per_row;
+    const int c = (int)(i - r * per_row);
+    const long sr = idx ? idx[r] : r * step;
+    reinterpret_cast<f32x4*>(dst + r * bytes)[c] = reinterpret_cast<const f32x4*>(src + sr * bytes)[c];
+  }
+}
+
 // out[g] = mean over the `group` consecutive rows of group g (template averaging of the zero-shot label prompts,
 // video_text_classification.py:88-90).  Sequential fp32 sum then one division, as torch.mean over a short axis.
 __global__ void __launch_bounds__(256) group_mean_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -423,16 +439,16 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
 
 int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
-                         int write_x, hipStream_t stream) {
+                         int write_x, int delta_compact, hipStream_t stream) {
   if (rows <= 0) return FC_OK;
   const int esz = kind == 1 ? 2 : 4;
   if ((x_stride % 4) || (d_stride * esz) % 8 || (y_stride * esz) % 8 ||
       (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta) & 15))
     return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned");
   return kind == 1 ? add_layernorm_dispatch<bf16>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows,
-                                                  D, write_x, stream)
+                                                  D, write_x, delta_compact, stream)
                    : add_layernorm_dispatch<float>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows,
-                                                   D, write_x, stream);
+                                                   D, write_x, delta_compact, stream);
 }
 
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream) {
@@ -483,6 +499,15 @@ int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int f
   if (frames <= 0 || dim <= 0 || dim > 1024) return fail(FC_EINVAL, "pool_normalize: frames=%d dim=%d", frames, dim);
   hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_clips), dim3(256), 0, stream, frame_emb, out, frames, dim);
   FC_CHECK_LAUNCH("pool_normalize");
+  return FC_OK;
+}
+
+int launch_gather_rows(const void* src, const int* idx, long step, void* dst, int n, int row_bytes, hipStream_t stream) {
+  if (n <= 0) return FC_OK;
+  if (row_bytes % 16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return fail(FC_EINVAL, "gather_rows: alignment");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(flat_blocks((size_t)n * (row_bytes >> 4))), dim3(256), 0, stream,
+                     (const char*)src, idx, step, (char*)dst, n, row_bytes);
+  FC_CHECK_LAUNCH("gather_rows");
   return FC_OK;
 }
 

@@ -63,6 +63,9 @@ typedef struct {
   int32_t chunk_frames;       /* frames per pass of the visual tower; 0 = default */
   int32_t chunk_texts;        /* texts per pass of the text tower;    0 = default */
   int32_t gemm_tile;          /* 0 = auto, 1 = 128x128, 2 = 256x256 (tuning / tests) */
+  int32_t prune_last_block;   /* 1: after the attention of the LAST block only the pooled rows (CLS / EOT) go through
+                                 out_proj, LayerNorm 2 and the MLP - nothing else is read afterwards; identical
+                                 embeddings, 6 % fewer FLOPs.  0 (default): every row, as the reference computes it */
 } fc_config;
 
 typedef struct fc_handle fc_handle;

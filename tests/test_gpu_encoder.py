@@ -328,3 +328,17 @@ def test_small_workspace_means_more_passes_not_different_results(tiny_state_dict
     rc = lib.fc_encode_image(rt.handle, images.data_ptr(), 9, ref.data_ptr(), tiny_ws.data_ptr(), tiny_ws.numel(),
                              _lib.current_stream())
     assert rc == -3 and b"workspace too small" in lib.fc_last_error()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pruned_last_block_is_bit_identical(vitb16_state_dict, precision):
+    """`prune_last_block` only skips rows nothing reads after the last block: embeddings must not change by one bit."""
+    d = synth.VIT_B_16
+    video = torch.from_numpy(synth.make_video(5, 2, d, seed=13)).to(DEV)
+    ids = torch.from_numpy(synth.make_text(7, d, seed=13)).to(DEV)
+    full = _encoder(vitb16_state_dict, precision)
+    pruned = _encoder(vitb16_state_dict, precision, prune_last_block=True)
+    assert torch.equal(pruned.encode_video(video), full.encode_video(video))
+    assert torch.equal(pruned.encode_text({"input_ids": ids}), full.encode_text({"input_ids": ids}))
+    assert torch.equal(pruned.encode_text({"input_ids": torch.from_numpy(synth.make_text(7, d, 14, all_random=True)).to(DEV)}),
+                       full.encode_text({"input_ids": torch.from_numpy(synth.make_text(7, d, 14, all_random=True)).to(DEV)}))
