@@ -461,13 +461,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           for (int j = 0; j < FN; ++j) mma<T>(wb[s & 1][j], xp[u & 1][a], acc[2 * p + a][j]);
         // pin the issue order hipcc would otherwise undo (it sinks the reads next to their first use): first the LDS
         // reads of the NEXT group, then this group's MFMAs
+        // Issue order inside a group: ONE MFMA first, then the LDS reads of the next group, then the other MFMAs.
+        // hipcc's s_waitcnt for this group's operands is an lgkmcnt(0) placed before the first MFMA; with the reads
+        // in front of it that wait would also cover the reads just issued (a full LDS latency per group).
         constexpr int kMfmaPerGroup = 2 * FN * (sizeof(T) == 2 ? 1 : 4);
-        if constexpr (u + 1 < NG) {
-          __builtin_amdgcn_sched_group_barrier(0x100, ((u + 1) % GPS == 0 ? FN : 0) + 2, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x100, FN + 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerGroup, 0);
+        constexpr int kReads = (u + 1 < NG) ? ((u + 1) % GPS == 0 ? FN : 0) + 2 : FN + 2;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerGroup - 1, 0);
       });
     }
     const bool interior = cm0 + BM <= g.M && cn0 + BN <= g.N;
