@@ -175,14 +175,17 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(const bf16* __restrict__
 //   * the 16x64 output tile is transposed through a private 2 KiB LDS patch and stored as 8 rows x 128 B per
 //     instruction; exp is a bare v_exp_f32 (scores pre-scaled by log2(e)/8).
 //   * NWAVES waves per workgroup, each owning q-tiles w, w + NWAVES, ... (7 waves for 13 visual q-tiles: 93 % balance).
-template <int NKT, int NWAVES, bool CAUSAL>
+template <int NKT, int NWAVES, bool CAUSAL, int NFULL>
 __global__ void __launch_bounds__(NWAVES * 64) attn_bf16_v2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                                   int S, int heads) {
   constexpr int NK = NKT * 16;
   constexpr int OFF_V = NK * 128;
   constexpr int OFF_O = 2 * NK * 128;  // NWAVES x 2 KiB output patches
   constexpr int MAXQ = 2;              // q-tiles per wave held in registers (Q fragments are preloaded)
+  constexpr int NVMIN = (NK / 8) / NWAVES;  // V pieces EVERY wave issues (some waves issue one more)
   static_assert(NKT % 2 == 0, "P.V consumes key tiles in pairs");
+  static_assert(NFULL >= 0 && NFULL <= NKT, "NFULL = key tiles known to be unmasked at compile time");
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -193,85 +196,117 @@ __global__ void __launch_bounds__(NWAVES * 64) attn_bf16_v2_kernel(const bf16* _
   const bf16* base = qkv + (long)seq * S * ld + h * 64;
   const bf16* Kg = base + D;
   const bf16* Vg = base + 2 * D;
-
-  // ---- stage K and V by LDS-DMA: one wave-instruction = 8 key rows x 128 B
-  {
-    const int rin = lane >> 3, pc = lane & 7;
-    for (int grp = wave; grp < 2 * (NK / 8); grp += NWAVES) {
-      const bool isv = grp >= NK / 8;
-      const int row = (isv ? grp - NK / 8 : grp) * 8 + rin;
-      const int srow = min(row, S - 1);  // padded keys read a valid row; they are masked / multiplied by P = 0
-      const int c = isv ? ((((pc >> 1) ^ ((row >> 1) & 3)) << 1) | (pc & 1)) : (pc ^ ((row >> 1) & 7));
-      const bf16* src = (isv ? Vg : Kg) + (long)srow * ld + c * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + grp * 1024), 16, 0, 0);
-    }
-  }
   const int r = lane & 15, q4 = lane >> 4, f = (r >> 1) & 7;
   const int nqt = (S + 15) >> 4;
-  // ---- Q fragments of this wave's q-tiles (B-operand of S^T = K.Q^T: lane holds 8 d of query r)
+
+  // ---- Q fragments of this wave's q-tiles (B-operand of S^T = K.Q^T: lane holds 8 d of query r), requested FIRST:
+  // vmcnt retires in order, so Q, then K, then V become available one after the other.
   bf16x8 qf[MAXQ][2];
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) {
     const int qt = wave + i * NWAVES;
     const int qrow = min(qt * 16 + r, S - 1);
+    // Spelled as asm: hipcc drains vmcnt to 0 before the first use of a register loaded while LDS-DMA ("flat") pieces
+    // are in flight, which would make the first softmax wait for V as well.  The registers are handed to the compiler
+    // by the counted wait below (its "+v" operands), never before.
 #pragma unroll
-    for (int s = 0; s < 2; ++s) qf[i][s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * ld + (4 * s + q4) * 8);
+    for (int s = 0; s < 2; ++s)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[i][s]) : "v"(base + (long)qrow * ld + (4 * s + q4) * 8) : "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // ---- stage K, then V, by LDS-DMA: one wave-instruction = 8 key rows x 128 B.  Fully unrolled with a compile-time
+  // count of unconditional pieces, so that hipcc's own wait for the Q registers stays a counted vmcnt.
+  {
+    const int rin = lane >> 3, pc = lane & 7;
+    constexpr int NPIECE = (NK / 8 + NWAVES - 1) / NWAVES;
+#pragma unroll
+    for (int isv = 0; isv < 2; ++isv) {
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) {
+        const int grp = wave + j * NWAVES;
+        if (j < NVMIN || grp < NK / 8) {
+          const int row = grp * 8 + rin;
+          const int srow = min(row, S - 1);  // padded keys read a valid row; they are masked / multiplied by P = 0
+          const int c = isv ? ((((pc >> 1) ^ ((row >> 1) & 3)) << 1) | (pc & 1)) : (pc ^ ((row >> 1) & 7));
+          const bf16* src = (isv ? Vg : Kg) + (long)srow * ld + c * 8;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)(smem + (isv ? OFF_V : 0) + grp * 1024), 16, 0, 0);
+        }
+      }
+    }
+  }
+  // Q and K have landed once at most the V pieces are outstanding; V is only needed after the first softmax.
+  static_assert(MAXQ == 2, "the wait below names every Q fragment");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[1][0]), "+v"(qf[1][1]) : "n"(NVMIN) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
   const float kScale = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
   char* patch = smem + OFF_O + wave * 2048;
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) {
     const int qt = wave + i * NWAVES;
-    if (qt >= nqt) break;
+    const bool active = qt < nqt;  // wave-uniform
     const int query = qt * 16 + r;
     f32x4 sT[NKT];
+    float inv = 0.f;
+    if (active) {
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (!CAUSAL || t <= qt) {
+      for (int t = 0; t < NKT; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bool dead = (t >= NFULL && t * 16 >= S) || (CAUSAL && t > qt);  // every key of the tile is masked
+        if (!dead) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + (t * 16 + r) * 128 + (((4 * s + q4) ^ f) << 4));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][s], acc, 0, 0, 0);
+          for (int s = 0; s < 2; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + (t * 16 + r) * 128 + (((4 * s + q4) ^ f) << 4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[i][s], acc, 0, 0, 0);
+          }
         }
+        sT[t] = acc;
       }
-      sT[t] = acc;
-    }
-    // scale, mask (only tiles that can contain masked keys), max
-    float mx = kNegInf;
+      // mask (only tiles that can contain masked keys) and row maximum of the RAW scores (the scale is positive)
+      float mx = kNegInf;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      const bool partial = (t * 16 + 16 > S) || (CAUSAL && t >= qt);
+      for (int t = 0; t < NKT; ++t) {
+        if (CAUSAL || t >= NFULL) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = sT[t][e] * kScale;
-        if (partial) {
-          const int key = t * 16 + 4 * q4 + e;
-          if (key >= S || (CAUSAL && key > query)) v = kNegInf;
+          for (int e = 0; e < 4; ++e) {
+            const int key = t * 16 + 4 * q4 + e;
+            if (key >= S || (CAUSAL && key > query)) sT[t][e] = kNegInf;
+          }
         }
-        sT[t][e] = v;
-        mx = fmaxf(mx, v);
+        // v_max3_f32 spelled out: `fmaxf` on raw MFMA results makes hipcc canonicalise every input first (IEEE mode),
+        // three times the instructions
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(sT[t][0]), "v"(sT[t][1]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(sT[t][2]), "v"(sT[t][3]));
       }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // p = exp2(s * c - mx * c): one packed fma per two scores, bare v_exp_f32, packed running sum
+      const f32x2 c2 = {kScale, kScale}, nm2 = {-mx * kScale, -mx * kScale};
+      f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float p = __builtin_amdgcn_exp2f(sT[t][e] - mx);
-        sT[t][e] = p;
-        sum += p;
+      for (int t = 0; t < NKT; ++t) {
+        f32x2 a = {sT[t][0], sT[t][1]}, b = {sT[t][2], sT[t][3]};
+        a = a * c2 + nm2;
+        b = b * c2 + nm2;
+        a = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        b = f32x2{__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+        sum2 += a;
+        sum2 += b;
+        sT[t] = f32x4{a[0], a[1], b[0], b[1]};
       }
+      float sum = sum2[0] + sum2[1];
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      inv = __builtin_amdgcn_rcpf(sum);
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
+    if (i == 0) {  // V has landed (every wave passes here exactly once, active or not)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (!active) continue;
 
     // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
     f32x4 o[4];
@@ -387,27 +422,29 @@ __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__
   }
 }
 
-template <int NKT, int NWAVES>
-int launch_bf16_v2(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
-  constexpr int NK = NKT * 16;
-  constexpr int lds = 2 * NK * 128 + NWAVES * 2048;
-  if ((S + 15) / 16 > 2 * NWAVES) return fail(FC_EINVAL, "attention(bf16): %d query tiles exceed the wave plan", (S + 15) / 16);
+template <int NKT, int NWAVES, bool CAUSAL, int NFULL>
+int launch_bf16_v2_variant(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
+  constexpr int lds = 2 * NKT * 16 * 128 + NWAVES * 2048;
   static bool configured = false;
   if (!configured && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)attn_bf16_v2_kernel<NKT, NWAVES, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bf16_v2_kernel<NKT, NWAVES, false>,
+    if (hipFuncSetAttribute((const void*)attn_bf16_v2_kernel<NKT, NWAVES, CAUSAL, NFULL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return fail(FC_ELAUNCH, "attention(bf16): cannot raise dynamic LDS");
     configured = true;
   }
-  const dim3 grid(n_seq * heads), block(NWAVES * 64);
-  if (causal)
-    hipLaunchKernelGGL((attn_bf16_v2_kernel<NKT, NWAVES, true>), grid, block, lds, st, (const bf16*)qkv, (bf16*)out, S, heads);
-  else
-    hipLaunchKernelGGL((attn_bf16_v2_kernel<NKT, NWAVES, false>), grid, block, lds, st, (const bf16*)qkv, (bf16*)out, S, heads);
+  hipLaunchKernelGGL((attn_bf16_v2_kernel<NKT, NWAVES, CAUSAL, NFULL>), dim3(n_seq * heads), dim3(NWAVES * 64), lds, st,
+                     (const bf16*)qkv, (bf16*)out, S, heads);
   FC_CHECK_LAUNCH("attention(bf16 v2)");
   return FC_OK;
+}
+
+template <int NKT, int NWAVES>
+int launch_bf16_v2(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
+  if ((S + 15) / 16 > 2 * NWAVES) return fail(FC_EINVAL, "attention(bf16): %d query tiles exceed the wave plan", (S + 15) / 16);
+  if (causal) return launch_bf16_v2_variant<NKT, NWAVES, true, 0>(qkv, out, n_seq, S, heads, st);
+  // sequences that need this key-tile count for real (the ViT: 197 tokens in 14 tiles) only mask the last two tiles
+  if (S > (NKT - 2) * 16) return launch_bf16_v2_variant<NKT, NWAVES, false, NKT - 2>(qkv, out, n_seq, S, heads, st);
+  return launch_bf16_v2_variant<NKT, NWAVES, false, 0>(qkv, out, n_seq, S, heads, st);
 }
 
 template <int NKT>
