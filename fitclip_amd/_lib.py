@@ -66,6 +66,7 @@ SIGNATURES = {
     "fc_attention": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "fc_convert": (_i32, [_vp, _vp, _i32, _sz, _vp]),
     "fc_profile_enable": (_i32, [_vp, _i32]),
+    "fc_profile_select": (_i32, [_vp, C.c_uint32, C.c_uint32]),
     "fc_profile_reset": (_i32, [_vp]),
     "fc_profile_read": (_i32, [_vp, C.POINTER(fc_prof_record), _i32]),
 }

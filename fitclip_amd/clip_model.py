@@ -191,6 +191,11 @@ class CLIP(nn.Module):
         rt = self._ensure_ready()
         _lib.check(_lib.load().fc_profile_enable(rt.handle, max_records), "fc_profile_enable")
 
+    def profile_select(self, kind_mask: int = 0xFFFFFFFF, epilogue_mask: int = 0xFFFFFFFF) -> None:
+        """Restricts the recorded launches (kind 0 = GEMM, 1 = attention, 2 = add+LayerNorm; GEMM epilogue ids)."""
+        _lib.check(_lib.load().fc_profile_select(self._ensure_ready().handle, kind_mask, epilogue_mask),
+                   "fc_profile_select")
+
     def profile_reset(self) -> None:
         _lib.check(_lib.load().fc_profile_reset(self._ensure_ready().handle), "fc_profile_reset")
 

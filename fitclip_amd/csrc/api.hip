@@ -58,6 +58,7 @@ struct fc_handle {
   std::vector<hipEvent_t> ev;
   std::vector<fc_prof_record> recs;
   int prof_cap = 0;
+  unsigned prof_kinds = ~0u, prof_epis = ~0u;  // fc_profile_select masks
 
   int vheads() const { return cfg.vision_width / 64; }
   int grid() const { return cfg.image_resolution / cfg.vision_patch_size; }
@@ -150,10 +151,20 @@ struct ProfScope {
   hipStream_t st;
   int idx = -1;
   ProfScope(fc_handle* h_, hipStream_t st_, int prec, int epi, int tile, const GemmArgs& a) : h(h_), st(st_) {
-    if (h && h->prof_cap && (int)h->recs.size() < h->prof_cap) {
+    if (h && h->prof_cap && (h->prof_kinds & 1u) && (h->prof_epis >> epi & 1u) && (int)h->recs.size() < h->prof_cap) {
       idx = (int)h->recs.size();
       fc_prof_record r{};
       r.kind = 0; r.precision = prec; r.epilogue = epi; r.tile = tile; r.M = a.M; r.N = a.N; r.K = a.K; r.ms = -1.f;
+      h->recs.push_back(r);
+      (void)hipEventRecord(h->ev[2 * idx], st);
+    }
+  }
+  // kind 1 = attention (M = sequences, N = heads, K = tokens), kind 2 = (add+)LayerNorm (M = rows, N = width, K = 0/1 = with add)
+  ProfScope(fc_handle* h_, hipStream_t st_, int kind, int M, int N, int K) : h(h_), st(st_) {
+    if (h && h->prof_cap && (h->prof_kinds >> kind & 1u) && (int)h->recs.size() < h->prof_cap) {
+      idx = (int)h->recs.size();
+      fc_prof_record r{};
+      r.kind = kind; r.precision = h->cfg.precision; r.epilogue = -1; r.tile = 0; r.M = M; r.N = N; r.K = K; r.ms = -1.f;
       h->recs.push_back(r);
       (void)hipEventRecord(h->ev[2 * idx], st);
     }
@@ -227,10 +238,14 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
     if (l == 0) {
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
     } else {
+      ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_add_layernorm(s.x, w, s.xn, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, 1, 0, st));
     }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, 0, st));
-    FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
+    {
+      ProfScope ps(h, st, 1, n_seq, heads, S);
+      FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
+    }
     if (l + 1 == nl && h->cfg.prune_last_block) {
       const size_t blk = align_up((size_t)n_seq * w * esz);
       char* ao = s.big;           // [n, w]  pooled rows of the attention output
@@ -246,7 +261,10 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
       return launch_add_layernorm(s.x, xs_pool, d2, w, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 1, st);
     }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.out_w, b.out_b, s.big, nullptr, M, w, w, w, 0, st));
-    FC_TRY(launch_add_layernorm(s.x, w, s.big, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, 1, 0, st));
+    {
+      ProfScope ps(h, st, 2, M, w, 1);
+      FC_TRY(launch_add_layernorm(s.x, w, s.big, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, 1, 0, st));
+    }
     FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
     FC_TRY(gemm(h, EPI_BIAS_T, s.big, b.proj_w, b.proj_b, s.xn, nullptr, M, w, 4 * w, w, 0, st));
   }
@@ -530,6 +548,12 @@ int fc_profile_enable(fc_handle* h, int32_t max_records) {
   }
   h->recs.reserve(max_records);
   h->prof_cap = max_records;
+  return FC_OK;
+}
+int fc_profile_select(fc_handle* h, uint32_t kind_mask, uint32_t epilogue_mask) {
+  if (!h) return fail(FC_EINVAL, "fc_profile_select: null handle");
+  h->prof_kinds = kind_mask;
+  h->prof_epis = epilogue_mask;
   return FC_OK;
 }
 int fc_profile_reset(fc_handle* h) {

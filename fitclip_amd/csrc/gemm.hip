@@ -1,4 +1,6 @@
 // Host-side dispatch of the MFMA GEMM (kernel: gemm_kernel.h).
+#include <cstdlib>
+
 #include "gemm_kernel.h"
 
 #include <algorithm>
@@ -37,11 +39,11 @@ int num_cus() {
 }
 
 // persistent, pipelined kernel: one workgroup per CU walks the tiles
-template <typename T, int EPI>
-int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
+template <typename T, int EPI, int SCHED>
+int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
   constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 32 * (BN / WN) : 0) + 2048;
-  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI>;
+  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, 0, 1, SCHED>;
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -53,6 +55,25 @@ int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(std::min(tiles, num_cus())), dim3(WM * WN * 64), lds, stream, a);
   FC_CHECK_LAUNCH("gemm(pipelined)");
   return FC_OK;
+}
+
+// LDS-DMA issue schedule (gemm_kernel.h: piece_slot), measured with tools/gemm_lab (profiles/r01_lab17_sched.log):
+// short-K GEMMs whose activation panel is re-read from L2 by 9-12 column tiles (QKV, out_proj, c_fc) gain 6-8 % from
+// spreading all pieces over the first two MFMA groups of the next K-step (8); the K = 3072 c_proj streams its
+// activations from HBM and wants them requested as early as possible (2: activations in the hand-over, weights spread).
+// FITCLIP_GEMM_SCHED=0|2|8 overrides (A/B runs); the result does not depend on the schedule.
+template <typename T, int EPI>
+int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
+  static const int forced = [] {
+    const char* e = getenv("FITCLIP_GEMM_SCHED");
+    return e ? atoi(e) : -1;
+  }();
+  const int sched = forced >= 0 ? forced : ((size_t)a.K * sizeof(T) > 2048 ? 2 : 8);
+  switch (sched) {
+    case 2: return launch_pipelined_sched<T, EPI, 2>(a, stream);
+    case 8: return launch_pipelined_sched<T, EPI, 8>(a, stream);
+    default: return launch_pipelined_sched<T, EPI, 0>(a, stream);
+  }
 }
 
 template <typename T>

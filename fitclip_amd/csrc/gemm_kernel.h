@@ -269,12 +269,27 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Issue slot of LDS-DMA piece idx (0..3 activation rows, 4..7 weight rows) under schedule `sched`; see the kernel.
+constexpr int piece_slot(int sched, int idx) {
+  switch (sched) {
+    case 1: return idx / 4;                          // group 0: A, group 1: W
+    case 2: return idx < 4 ? -1 : 0;                 // A in the hand-over, W after group 0
+    case 3: return idx < 4 ? -1 : 1;                 // A in the hand-over, W after group 1
+    case 4: return idx < 4 ? -1 : (idx - 4) / 2;     // A in the hand-over, W over groups 0, 1
+    case 5: return idx < 4 ? 0 : 1 + (idx - 4) / 2;  // A after group 0, W over groups 1, 2
+    case 6: return idx < 2 ? -1 : (idx - 2) / 2;     // 2 in the hand-over, 2 after each of groups 0..2
+    case 7: return idx / 2;                          // 2 after each of groups 0..3
+    case 8: return idx < 4 ? 1 : 0;                  // group 0: W, group 1: A
+    default: return -1;                              // everything in the hand-over
+  }
+}
+
 // The K loop is software pipelined: the MFMAs of a K-tile are issued in FM groups of 2*FN; the LDS reads of group
 // u+1 are issued before the MFMAs of group u (pinned with sched_group_barrier: hipcc otherwise sinks the reads next
 // to their first use), and the hand-over to the next K-tile (wait for its DMA, barrier, issue the DMA two tiles ahead,
 // first fragment reads) sits in front of the LAST group of the current tile, so neither LDS latency nor the barrier
 // leaves the matrix pipe idle.  The accumulators start from the bias slice (no bias registers in the epilogue).
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0, int ROT = 1>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0, int ROT = 1, int SCHED = 0>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const GemmArgs g) {
   constexpr int NW = WM * WN;
   constexpr int BKE = ROWB / (int)sizeof(T);
@@ -380,6 +395,33 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[i] + (unsigned)kt * ROWB)),
           (__attribute__((address_space(3))) void*)(dst + BM * ROWB + i * NW * 1024), 16, 0, 0);
   };
+  // One LDS-DMA piece of a stage (idx < LPA: activation rows, else weight rows): lets the K loop spread the pieces of a
+  // K-tile over its MFMA groups instead of issuing them in one burst.
+  auto stage_piece = [&](int stage, int kt, auto IDX) {
+    constexpr int idx = decltype(IDX)::value;
+    kt += rot;
+    if (kt >= nk) kt -= nk;
+    char* dst = smem + stage * STAGE + wave * 1024;
+    if constexpr (idx < LPA)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[idx] + (unsigned)kt * ROWB)),
+          (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[idx - LPA] + (unsigned)kt * ROWB)),
+          (__attribute__((address_space(3))) void*)(dst + BM * ROWB + (idx - LPA) * NW * 1024), 16, 0, 0);
+  };
+  // SCHED > 0: the LDS-DMA pieces of the K-tile needed two steps ahead are not issued as one burst of LPW pieces inside
+  // the hand-over; piece idx goes to slot piece_slot(SCHED, idx): -1 = still in the hand-over, u >= 0 = after MFMA
+  // group u of the NEXT K-step (the stage it lands in was released by the hand-over barrier that precedes that step).
+  // Each piece blocks its wave's issue port for ~100 cycles, and right after the barrier the two waves of a SIMD would
+  // both be in that burst, with nobody feeding the matrix pipe.
+  static_assert(SCHED == 0 || LPW == 8, "piece schedules are written for 8 pieces per wave");
+  auto handover_pieces = [&](int stage, int kt) {
+    static_for<LPW>([&](auto I) {
+      if constexpr (piece_slot(SCHED, decltype(I)::value) < 0) stage_piece(stage, kt, I);
+    });
+  };
   auto bias_load = [&](int buf, int n0) {  // BN floats -> LDS by one LDS-DMA of wave 0 (part of that tile's first load)
     if (wave == 0) {
       const float* p = g.bias + min(n0 + lane * 4, g.N - 4);
@@ -459,14 +501,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           block_barrier();
           if (ABL != 1) {
             if (kt + 2 < nk) {
-              stage_load(sidx, kt + 2);
+              handover_pieces(sidx, kt + 2);
             } else if (has_next) {
               if (kt + 2 == nk) {
                 tile_sources(tnext, m0, n0);
                 bias_load((it + 1) & 1, n0);
-                stage_load(sidx, 0);
+                handover_pieces(sidx, 0);
               } else {
-                stage_load(sidx, 1);
+                stage_load(sidx, 1);  // always a burst: it has to be older than the epilogue stores (counted vmcnt)
               }
             }
           }
@@ -481,6 +523,20 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int j = 0; j < FN; ++j) mma<T>(wb[s & 1][j], xp[u & 1][a], acc[2 * p + a][j]);
+        if constexpr (SCHED > 0 && ABL != 1 && u + 1 < NG) {
+          constexpr bool any = piece_slot(SCHED, 0) == u || piece_slot(SCHED, 1) == u || piece_slot(SCHED, 2) == u ||
+                               piece_slot(SCHED, 3) == u || piece_slot(SCHED, 4) == u || piece_slot(SCHED, 5) == u ||
+                               piece_slot(SCHED, 6) == u || piece_slot(SCHED, 7) == u;
+          if constexpr (any) {
+            // K-tile kt+1 (or K-tile 0 of the next output tile) into the stage the previous K-step has released
+            if (kt > 0 && (kt + 1 < nk || has_next)) {
+              const int lk = kt + 1 < nk ? kt + 1 : 0;
+              static_for<LPW>([&](auto I) {
+                if constexpr (piece_slot(SCHED, decltype(I)::value) == u) stage_piece(sidx ^ 1, lk, I);
+              });
+            }
+          }
+        }
         // pin the issue order hipcc would otherwise undo (it sinks the reads next to their first use): first the LDS
         // reads of the NEXT group, then this group's MFMAs
         // Issue order inside a group: ONE MFMA first, then the LDS reads of the next group, then the other MFMAs.

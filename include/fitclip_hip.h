@@ -153,9 +153,10 @@ FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
 
-/* ---- kernel timing (bench.py roofline leg): hipEvent pairs around every GEMM launch on the caller's stream ------ */
+/* ---- kernel timing (bench.py roofline leg): hipEvent pairs around the GEMM, attention and add+LayerNorm launches
+ * of the transformer blocks, on the caller's stream ----------------------------------------------------------------- */
 typedef struct {
-  int32_t kind;      /* 0 = gemm */
+  int32_t kind;      /* 0 = gemm (M,N,K); 1 = attention (M = sequences, N = heads, K = tokens); 2 = add+LayerNorm (M = rows, N = width) */
   int32_t precision; /* fc_precision */
   int32_t epilogue;
   int32_t tile;
@@ -163,6 +164,10 @@ typedef struct {
   float ms;          /* elapsed between the two events; valid after the stream has been synchronised */
 } fc_prof_record;
 FC_API int fc_profile_enable(fc_handle* h, int32_t max_records); /* 0 disables and frees the events */
+/* Only launches with (kind_mask >> kind) & 1 and, for GEMMs, (epilogue_mask >> epilogue) & 1 are recorded (default: all).
+ * An event pair costs a few microseconds of dispatch serialisation per launch: a timed run keeps only the kernel it
+ * reports on. */
+FC_API int fc_profile_select(fc_handle* h, uint32_t kind_mask, uint32_t epilogue_mask);
 FC_API int fc_profile_reset(fc_handle* h);
 FC_API int fc_profile_read(fc_handle* h, fc_prof_record* out, int32_t max_records); /* returns the record count */
 

@@ -85,10 +85,10 @@ void launch_plain(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, st, a);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL, int ROT = 0>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL, int ROT = 0, int SCHED = 0>
 void launch_pipelined(const GemmArgs& a, hipStream_t st) {
   constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 32 * (BN / WN) : 0) + 2048;
-  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, ABL, ROT>;
+  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, ABL, ROT, SCHED>;
   static bool configured = false;
   if (!configured) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
