@@ -1,0 +1,139 @@
+"""On-disk formats either side of the encoder: Lightning `.ckpt` files and bare OpenAI-CLIP-named state dicts.
+
+Mirrors (behaviour, not code):
+  * `util/checkpoint_utils.py:9-12`  -> `state_dict_from_checkpoint_path`: `checkpoint["state_dict"]` filtered by a key
+    prefix (a missing trailing dot is added), prefix stripped;
+  * `scripts/checkpoint_to_state_dict.py` -> `python -m fitclip_amd.checkpoint INPUT [--prefix encoder.model.] > out.pt`;
+  * `aligner/text_video_retrieval.py:101-131` -> `load_module_state_dict`: a plain retrieval module silently drops the
+    `teacher*` keys of a teacher-student checkpoint, and reports the other mismatches with torch's own wording;
+  * the module-level keys a Lightning checkpoint of the reference holds: `encoder.<param>`, `logit_scale`, and for the
+    distillation module `teacher.<param>`, `teacher_student_logit_scale` (`aligner/video_text_module.py:32`,
+    `aligner/teacher_student.py:55,70`).
+
+Only LOCAL paths are read (there is no egress; the reference's `cached_path(url)` fetch has no counterpart).  A path
+may be a pipe (process substitution), as in the reference's README recipes: it is drained into memory first because
+`torch.load` needs a seekable file (`clip_video_text_encoder.py:35-41` copies it to a temp file for the same reason).
+"""
+from __future__ import annotations
+
+import argparse
+import io
+import math
+import os
+import sys
+from collections import OrderedDict
+from typing import Any, Dict, List, Mapping, MutableMapping, NamedTuple, Union
+
+import torch
+
+TYPE_PATH = Union[str, "os.PathLike[str]"]
+
+
+def _load(path: TYPE_PATH) -> Any:
+    path = os.fspath(path)
+    if "://" in path:
+        raise FileNotFoundError(f"{path!r}: remote checkpoints cannot be fetched here (no network); pass a local file")
+    if os.path.exists(path) and not os.path.isdir(path) and not os.path.isfile(path):  # a pipe
+        with open(path, "rb") as f:
+            return torch.load(io.BytesIO(f.read()), map_location="cpu", weights_only=False)
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_state_dict_file(path: TYPE_PATH) -> MutableMapping[str, torch.Tensor]:
+    """A bare state dict, or the `state_dict` of a Lightning checkpoint with the `encoder.model.` prefix stripped."""
+    obj = _load(path)
+    if isinstance(obj, Mapping) and "state_dict" in obj and isinstance(obj["state_dict"], Mapping):
+        return strip_prefix(obj["state_dict"], "encoder.model.")
+    return obj
+
+
+def strip_prefix(state_dict: Mapping[str, torch.Tensor], prefix: str = "") -> MutableMapping[str, torch.Tensor]:
+    prefix += "" if prefix.endswith(".") or not prefix else "."
+    return {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+
+
+def state_dict_from_checkpoint_path(checkpoint_path: TYPE_PATH, prefix: str = "") -> MutableMapping[str, torch.Tensor]:
+    return strip_prefix(_load(checkpoint_path)["state_dict"], prefix)
+
+
+# ------------------------------------------------------------------------------------------- module <-> state dict
+class IncompatibleKeys(NamedTuple):
+    missing_keys: List[str]
+    unexpected_keys: List[str]
+
+
+def _scalar(v: float) -> torch.Tensor:
+    return torch.tensor(float(v))
+
+
+def module_state_dict(module: Any) -> "OrderedDict[str, torch.Tensor]":
+    """The keys a Lightning checkpoint of the reference's module holds for the same object graph."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    sd["logit_scale"] = _scalar(module.logit_scale)
+    for k, v in module.encoder.state_dict().items():
+        sd[f"encoder.{k}"] = v
+    teacher = getattr(module, "teacher", None)
+    if teacher is not None:
+        for k, v in teacher.state_dict().items():
+            sd[f"teacher.{k}"] = v
+        sd["teacher_student_logit_scale"] = _scalar(module.teacher_student_logit_scale)
+    return sd
+
+
+def save_checkpoint(module: Any, path: TYPE_PATH, **extra: Any) -> None:
+    """Writes `{"state_dict": ...}` (the part of a Lightning checkpoint the reference's tools read)."""
+    torch.save({"state_dict": module_state_dict(module), **extra}, os.fspath(path))
+
+
+def load_module_state_dict(module: Any, state_dict: Mapping[str, torch.Tensor], strict: bool = True) -> IncompatibleKeys:
+    """`load_state_dict` of the module family in `fitclip_amd.retrieval`.
+
+    A module WITHOUT a teacher ignores every key that starts with "teacher" (so a distillation checkpoint can be
+    evaluated with the plain retrieval module, text_video_retrieval.py:104-111); everything else follows
+    `nn.Module.load_state_dict`: with `strict`, missing / unexpected keys raise a RuntimeError with torch's wording.
+    """
+    own = module_state_dict(module)
+    has_teacher = getattr(module, "teacher", None) is not None
+    unexpected = [k for k in state_dict if k not in own and (has_teacher or not k.startswith("teacher"))]
+    missing = [k for k in own if k not in state_dict]
+    if strict and (unexpected or missing):
+        msgs = []
+        if unexpected:
+            msgs.append("Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ". ")
+        if missing:
+            msgs.append("Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ". ")
+        raise RuntimeError(f"Error(s) in loading state_dict for {type(module).__name__}:\n\t" + "\n\t".join(msgs))
+
+    def sub(prefix: str) -> Dict[str, torch.Tensor]:
+        return {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix) and k in own}
+
+    if "logit_scale" in state_dict:
+        module.logit_scale = float(state_dict["logit_scale"])
+    enc = sub("encoder.")
+    if enc:
+        module.encoder.load_state_dict(enc, strict=False)
+    if has_teacher:
+        tch = sub("teacher.")
+        if tch:
+            module.teacher.load_state_dict(tch, strict=False)
+        if "teacher_student_logit_scale" in state_dict:
+            module.teacher_student_logit_scale = float(state_dict["teacher_student_logit_scale"])
+    assert not math.isnan(module.logit_scale), "a checkpoint's module-level logit_scale is never NaN"
+    return IncompatibleKeys(missing, unexpected)
+
+
+def load_checkpoint(module: Any, path: TYPE_PATH, strict: bool = True) -> IncompatibleKeys:
+    return load_module_state_dict(module, _load(path)["state_dict"], strict=strict)
+
+
+# ----------------------------------------------------------------------------------------------------------- CLI
+def main(argv: Union[List[str], None] = None) -> None:
+    parser = argparse.ArgumentParser(description="Lightning checkpoint -> bare (prefix-stripped) state dict on stdout")
+    parser.add_argument("input_path", metavar="INPUT_FILE")
+    parser.add_argument("--prefix", default="encoder.model.")
+    args = parser.parse_args(argv)
+    torch.save(state_dict_from_checkpoint_path(args.input_path, prefix=args.prefix), sys.stdout.buffer)
+
+
+if __name__ == "__main__":
+    main()

@@ -248,8 +248,5 @@ def load_clip_model(name: str, precision: str = "bf16", device: Optional[Union[s
         return build_clip(sd, precision=precision, device=device, **kwargs)
     if "://" in name or not os.path.exists(name):
         raise FileNotFoundError(f"{name!r}: only local state-dict files or 'synthetic[:seed]' can be loaded offline")
-    sd = torch.load(name, map_location="cpu")
-    if "state_dict" in sd:  # a Lightning checkpoint: strip the `encoder.model.` prefix (util/checkpoint_utils.py:9-12)
-        pre = "encoder.model."
-        sd = {k[len(pre):]: v for k, v in sd["state_dict"].items() if k.startswith(pre)}
-    return build_clip(sd, precision=precision, device=device, **kwargs)
+    from .checkpoint import load_state_dict_file  # bare state dict, Lightning .ckpt (prefix stripped) or a pipe
+    return build_clip(load_state_dict_file(name), precision=precision, device=device, **kwargs)

@@ -39,6 +39,16 @@ class VideoTextModule:
         scale = math.exp(min(self.logit_scale, self.max_logit_scale))
         return ops.similarity(encoded_video, encoded_text, alpha=scale)
 
+    def state_dict(self) -> "Dict[str, torch.Tensor]":
+        """Keys of the reference module's Lightning checkpoint: `logit_scale`, `encoder.*` (+ `teacher.*`)."""
+        from .checkpoint import module_state_dict
+        return module_state_dict(self)
+
+    def load_state_dict(self, state_dict: "Dict[str, torch.Tensor]", strict: bool = True):
+        """A module without a teacher ignores `teacher*` keys (text_video_retrieval.py:101-131)."""
+        from .checkpoint import load_module_state_dict
+        return load_module_state_dict(self, state_dict, strict=strict)
+
     def predict_step(self, batch: TYPE_INPUT) -> Dict[str, Any]:
         video_ids = batch.get("video_id")
         encoded_video, encoded_text = self(dict(batch))

@@ -1,0 +1,134 @@
+"""Checkpoint formats either side of the path (CPU only): Lightning `.ckpt` -> prefix-stripped state dict, the
+missing-`logit_scale` case, pipes, teacher-key filtering.  Mirrors `util/checkpoint_utils.py:9-12`,
+`scripts/checkpoint_to_state_dict.py`, `clip_video_text_encoder.py:30-61`, `text_video_retrieval.py:101-131`."""
+import io
+import math
+import os
+import subprocess
+import sys
+import threading
+
+import pytest
+import torch
+
+from fitclip_amd import checkpoint as C
+from fitclip_amd import synth
+from fitclip_amd.clip_model import build_clip, load_clip_model
+from fitclip_amd.encoder import ClipVideoTextEncoder
+from fitclip_amd.retrieval import TeacherStudentModule, TextVideoRetrievalModule
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _encoder(seed):
+    return ClipVideoTextEncoder(build_clip(synth.make_state_dict(synth.TINY, seed=seed), precision="fp32"), num_frames=2)
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(torch.as_tensor(a[k]), torch.as_tensor(b[k])), k
+
+
+def test_prefix_strip_adds_missing_dot(tmp_path):
+    ckpt = {"state_dict": {"encoder.model.a": torch.ones(2), "encoder.model.b.c": torch.zeros(1),
+                           "encoder.modelx": torch.ones(1), "logit_scale": torch.tensor(3.0)}}
+    path = tmp_path / "m.ckpt"
+    torch.save(ckpt, path)
+    for prefix in ("encoder.model", "encoder.model."):
+        assert sorted(C.state_dict_from_checkpoint_path(path, prefix)) == ["a", "b.c"]
+    assert sorted(C.state_dict_from_checkpoint_path(path)) == sorted(ckpt["state_dict"])  # empty prefix: everything
+
+
+def test_module_checkpoint_round_trip_and_cli(tmp_path):
+    student, teacher = _encoder(1), _encoder(2)
+    module = TeacherStudentModule(student, teacher, init_temperature=0.07)
+    module.teacher_student_logit_scale = 1.25
+    path = tmp_path / "ts.ckpt"
+    C.save_checkpoint(module, path, epoch=3)
+    sd = torch.load(path, weights_only=False)["state_dict"]
+    assert "encoder.model.visual.conv1.weight" in sd and "teacher.model.ln_final.bias" in sd
+    assert float(sd["teacher_student_logit_scale"]) == 1.25
+
+    # the conversion script: stdout carries a bare OpenAI-named state dict of the STUDENT
+    out = subprocess.run([sys.executable, "-m", "fitclip_amd.checkpoint", str(path)], cwd=REPO, check=True,
+                         capture_output=True).stdout
+    bare = torch.load(io.BytesIO(out), weights_only=False)
+    _same(bare, student.model.state_dict())
+    out = subprocess.run([sys.executable, "-m", "fitclip_amd.checkpoint", str(path), "--prefix", "teacher.model"],
+                         cwd=REPO, check=True, capture_output=True).stdout
+    _same(torch.load(io.BytesIO(out), weights_only=False), teacher.model.state_dict())
+
+    # load_clip_model accepts both the bare file and the Lightning checkpoint
+    bare_path = tmp_path / "student.pt"
+    torch.save(bare, bare_path)
+    # (the encoder drops CLIP's own `logit_scale`, so the files lack it and the loader re-creates it as NaN)
+    for p in (bare_path, path):
+        loaded = dict(load_clip_model(str(p), precision="fp32").state_dict())
+        assert math.isnan(float(loaded.pop("logit_scale")))
+        _same(loaded, student.model.state_dict())
+
+
+def test_missing_logit_scale_becomes_nan(tmp_path):
+    sd = {k: v for k, v in build_clip(synth.make_state_dict(synth.TINY, seed=3), precision="fp32").state_dict().items()
+          if k != "logit_scale"}
+    path = tmp_path / "no_scale.pt"
+    torch.save(sd, path)
+    model = load_clip_model(str(path), precision="fp32")
+    assert math.isnan(float(model.logit_scale))  # clip_video_text_encoder.py:43-53
+
+
+def test_pipe_is_accepted(tmp_path):
+    sd = _encoder(4).model.state_dict()
+    fifo = tmp_path / "fifo"
+    os.mkfifo(fifo)
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+
+    def writer():
+        with open(fifo, "wb") as f:
+            f.write(buf.getvalue())
+
+    t = threading.Thread(target=writer)
+    t.start()
+    model = load_clip_model(str(fifo), precision="fp32")
+    t.join()
+    loaded = dict(model.state_dict())
+    assert math.isnan(float(loaded.pop("logit_scale")))
+    _same(loaded, sd)
+
+
+def test_remote_names_are_rejected():
+    with pytest.raises(FileNotFoundError):
+        load_clip_model("https://example.invalid/model.pt")
+    with pytest.raises(FileNotFoundError):
+        load_clip_model("ViT-B/16")
+
+
+def test_retrieval_module_ignores_teacher_keys_only():
+    student, teacher = _encoder(5), _encoder(6)
+    ts = TeacherStudentModule(student, teacher)
+    ts.logit_scale = 2.5
+    sd = ts.state_dict()
+
+    plain = TextVideoRetrievalModule(_encoder(7))
+    res = plain.load_state_dict(sd)  # strict: teacher.* and teacher_student_logit_scale are dropped silently
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    assert plain.logit_scale == 2.5
+    _same(plain.encoder.state_dict(), student.state_dict())
+
+    bad = dict(sd)
+    bad["something_else"] = torch.zeros(1)
+    del bad["encoder.model.ln_final.weight"]
+    with pytest.raises(RuntimeError) as e:
+        plain.load_state_dict(bad)
+    msg = str(e.value)
+    assert msg.startswith("Error(s) in loading state_dict for TextVideoRetrievalModule:")
+    assert 'Unexpected key(s) in state_dict: "something_else". ' in msg
+    assert 'Missing key(s) in state_dict: "encoder.model.ln_final.weight". ' in msg
+    res = plain.load_state_dict(bad, strict=False)
+    assert res.unexpected_keys == ["something_else"] and res.missing_keys == ["encoder.model.ln_final.weight"]
+
+    # the distillation module itself does NOT ignore them: a plain checkpoint lacks its teacher
+    with pytest.raises(RuntimeError, match="Missing key"):
+        TeacherStudentModule(_encoder(8), _encoder(9)).load_state_dict(plain.state_dict())
