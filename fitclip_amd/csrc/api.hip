@@ -65,6 +65,11 @@ struct fc_handle {
   int patches() const { return grid() * grid(); }
   int vtokens() const { return patches() + 1; }
   int patch_k() const { return 3 * cfg.vision_patch_size * cfg.vision_patch_size; }
+  // the patch-embed GEMM's K: 3 p^2 padded to the kernel's K-tile (64 bf16 / 32 f32 elements); ViT-L/14: 588 -> 640
+  int patch_kp() const {
+    const int gran = cfg.precision == FC_PREC_BF16 ? 64 : 32;
+    return (patch_k() + gran - 1) / gran * gran;
+  }
   const float* w(const std::string& n) const { return slots.at(n).ptr; }
 };
 
@@ -123,27 +128,38 @@ size_t numel(const std::vector<int64_t>& s) {
   return n;
 }
 
-// GEMM weights that get a kernel-layout copy: (name, transpose?)
-std::vector<std::pair<std::string, bool>> packed_list(const fc_handle* h) {
-  std::vector<std::pair<std::string, bool>> l;
+// GEMM weights that get a kernel-layout copy
+enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS };
+struct PackItem {
+  std::string name;
+  PackMode mode;
+};
+std::vector<PackItem> packed_list(const fc_handle* h) {
+  std::vector<PackItem> l;
   const bool conv = h->cfg.precision == FC_PREC_BF16;  // f32 mode uses the caller's tensors directly
   auto blocks = [&](const std::string& prefix, int layers) {
     for (int i = 0; i < layers; ++i) {
       const std::string b = prefix + ".resblocks." + std::to_string(i);
-      l.push_back({b + ".attn.in_proj_weight", false});
-      l.push_back({b + ".attn.out_proj.weight", false});
-      l.push_back({b + ".mlp.c_fc.weight", false});
-      l.push_back({b + ".mlp.c_proj.weight", false});
+      l.push_back({b + ".attn.in_proj_weight", PACK_CONVERT});
+      l.push_back({b + ".attn.out_proj.weight", PACK_CONVERT});
+      l.push_back({b + ".mlp.c_fc.weight", PACK_CONVERT});
+      l.push_back({b + ".mlp.c_proj.weight", PACK_CONVERT});
     }
   };
+  const bool padded = h->patch_kp() != h->patch_k();
+  if (conv || padded) l.push_back({"visual.conv1.weight", padded ? PACK_PAD_ROWS : PACK_CONVERT});
   if (conv) {
-    l.push_back({"visual.conv1.weight", false});
     blocks("visual.transformer", h->cfg.vision_layers);
     blocks("transformer", h->cfg.transformer_layers);
   }
-  l.push_back({"visual.proj", true});
-  l.push_back({"text_projection", true});
+  l.push_back({"visual.proj", PACK_TRANSPOSE});
+  l.push_back({"text_projection", PACK_TRANSPOSE});
   return l;
+}
+size_t packed_item_bytes(const fc_handle* h, const PackItem& e) {
+  const auto& shape = h->slots.at(e.name).shape;
+  const size_t n = e.mode == PACK_PAD_ROWS ? (size_t)shape[0] * h->patch_kp() : numel(shape);
+  return align_up(n * h->esz);
 }
 
 struct ProfScope {
@@ -279,7 +295,7 @@ int default_chunk(const fc_handle* h, int tower) {
 
 size_t per_item_bytes(const fc_handle* h, int tower) {
   const fc_config& c = h->cfg;
-  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_k()).total;
+  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_kp()).total;
   return carve(nullptr, 1, c.context_length, c.transformer_width, h->esz, 0).total;
 }
 
@@ -301,21 +317,17 @@ int fc_create(const fc_config* cfg, fc_handle** out) {
     return fail(FC_EINVAL, "fc_create: widths must be positive multiples of 64 (head dim 64)");
   if (c.transformer_heads * 64 != c.transformer_width)
     return fail(FC_EINVAL, "fc_create: transformer_heads * 64 must equal transformer_width");
-  if (c.vision_patch_size <= 0 || c.image_resolution % c.vision_patch_size || c.vision_patch_size % 4)
+  if (c.vision_patch_size <= 0 || c.image_resolution <= 0 || c.image_resolution % c.vision_patch_size)
     return fail(FC_EINVAL, "fc_create: resolution %d / patch %d", c.image_resolution, c.vision_patch_size);
   if (c.embed_dim % 4 || c.embed_dim <= 0 || c.vision_layers <= 0 || c.transformer_layers <= 0 ||
       c.context_length <= 0 || c.vocab_size <= 0)
     return fail(FC_EINVAL, "fc_create: bad dimension");
-  const int kmult = c.precision == FC_PREC_BF16 ? 64 : 32;
-  if ((3 * c.vision_patch_size * c.vision_patch_size) % kmult)
-    return fail(FC_EINVAL, "fc_create: 3*patch^2 must be a multiple of %d", kmult);
   auto h = std::make_unique<fc_handle>();
   h->cfg = c;
   h->esz = c.precision == FC_PREC_BF16 ? 2 : 4;
   build_names(h.get());
-  const int vt = h->vtokens();
-  if ((c.precision == FC_PREC_BF16 && (vt > 224 || c.context_length > 224)))
-    return fail(FC_EINVAL, "fc_create: sequences longer than 224 tokens are not supported in bf16 mode");
+  if (c.precision == FC_PREC_BF16 && c.context_length > 224)
+    return fail(FC_EINVAL, "fc_create: text contexts longer than 224 tokens are not supported in bf16 mode");
   *out = h.release();
   return FC_OK;
 }
@@ -350,7 +362,7 @@ int fc_set_weight(fc_handle* h, const char* name, const float* dev, const int64_
 size_t fc_packed_bytes(const fc_handle* h) {
   if (!h) return 0;
   size_t total = 0;
-  for (auto& e : packed_list(h)) total += align_up(numel(h->slots.at(e.first).shape) * h->esz);
+  for (auto& e : packed_list(h)) total += packed_item_bytes(h, e);
   return total;
 }
 
@@ -364,15 +376,17 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
   std::map<std::string, const void*> packed;
   size_t off = 0;
   for (auto& e : packed_list(h)) {
-    const auto& slot = h->slots.at(e.first);
+    const auto& slot = h->slots.at(e.name);
     void* dst = static_cast<char*>(arena) + off;
-    if (e.second) {
+    if (e.mode == PACK_TRANSPOSE) {
       FC_TRY(launch_transpose_convert(slot.ptr, dst, kind, (int)slot.shape[0], (int)slot.shape[1], stream));
+    } else if (e.mode == PACK_PAD_ROWS) {
+      FC_TRY(launch_convert_rows(slot.ptr, dst, kind, (long)slot.shape[0], h->patch_k(), h->patch_kp(), stream));
     } else {
       FC_TRY(launch_convert(slot.ptr, dst, kind, numel(slot.shape), stream));
     }
-    packed[e.first] = dst;
-    off += align_up(numel(slot.shape) * h->esz);
+    packed[e.name] = dst;
+    off += packed_item_bytes(h, e);
   }
   auto gw = [&](const std::string& n) -> const void* {
     auto it = packed.find(n);
@@ -404,7 +418,7 @@ size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n) {
   if (!h || n <= 0 || tower < 0 || tower > 1) return 0;
   const int c = std::min(n, default_chunk(h, tower));
   const fc_config& k = h->cfg;
-  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_k()).total
+  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp()).total
                     : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0).total;
 }
 
@@ -416,7 +430,7 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
   if (n < 0 || !frames || !out || !ws) return fail(FC_EINVAL, "fc_encode_image: bad argument");
   if (((uintptr_t)frames | (uintptr_t)out | (uintptr_t)ws) & 15) return fail(FC_EINVAL, "fc_encode_image: unaligned pointer");
   const fc_config& c = h->cfg;
-  const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_k();
+  const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_kp();
   const size_t per = per_item_bytes(h, 0);
   int chunk = std::min(n, default_chunk(h, 0));
   if (carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) {  // smaller workspace: as many items as fit
@@ -429,7 +443,7 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     const int cn = std::min(chunk, n - off);
     const Scratch s = carve(static_cast<char*>(ws), cn, T, vw, h->esz, Kp);
     const float* f = frames + (size_t)off * 3 * R * R;
-    FC_TRY(launch_im2col(f, s.big, kind, cn, R, c.vision_patch_size, st));
+    FC_TRY(launch_im2col(f, s.big, kind, cn, R, c.vision_patch_size, Kp, st));
     FC_TRY(gemm(h, EPI_PATCH_F32, s.big, h->conv_w, nullptr, s.x, h->w("visual.positional_embedding"), cn * P, vw, Kp,
                 vw, P, st));
     FC_TRY(launch_cls_pos(s.x, h->w("visual.class_embedding"), h->w("visual.positional_embedding"), cn, T, vw, st));

@@ -19,6 +19,8 @@
 //
 // f32 kernel (parity path): plain VALU, one thread per query row, K/V broadcast from LDS, online softmax in fp32.
 #include "common.h"
+
+#include <algorithm>
 #include <cstdlib>
 
 namespace fc {
@@ -354,38 +356,200 @@ __global__ void __launch_bounds__(NWAVES * 64) attn_bf16_v2_kernel(const bf16* _
   }
 }
 
-// f32 parity kernel: thread per query, K/V rows broadcast from LDS.
+// ---- long sequences (S > 224: ViT-L/14 has 257 tokens, ViT-L/14@336 577): K/V do not fit LDS next to a second
+// workgroup, so they stream through a 2-deep ring of 64-key tiles with an online softmax (running max / sum per query,
+// accumulator rescaled when the max moves).  Same operand layouts, swizzles and MFMA shapes as attn_bf16_v2_kernel; one
+// 16-query tile per wave, NW waves per workgroup, grid = sequences x heads x query blocks.  Non-causal only (CLIP's
+// text context is 77).  Per K/V tile: wait for its DMA, barrier, issue the next tile's DMA (lands under this tile's
+// math), S^T = K.Q^T, mask, softmax update, O^T += V^T.P^T.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bf16_flash_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                 int S, int heads, int nqb) {
+  constexpr int TK = 64;                 // keys per tile
+  constexpr int STAGE = 2 * TK * 128;    // K tile + V tile
+  constexpr int OFF_O = 2 * STAGE;
+  constexpr int NPIECE = (2 * TK / 8 + NW - 1) / NW;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = blockIdx.x % nqb, sh = blockIdx.x / nqb;
+  const int seq = sh / heads, h = sh - seq * heads;
+  const int D = heads * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)seq * S * ld + h * 64;
+  const bf16* Kg = base + D;
+  const bf16* Vg = base + 2 * D;
+  const int r = lane & 15, q4 = lane >> 4, f = (r >> 1) & 7;
+  const int nqt = (S + 15) >> 4, nkt = (S + TK - 1) / TK;
+  const int qt = qb * NW + wave;
+  const bool active = qt < nqt;  // wave-uniform; inactive waves still stage tiles and take every barrier
+
+  bf16x8 qf[2];
+  {
+    const int qrow = min(qt * 16 + r, S - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * ld + (4 * s + q4) * 8);
+  }
+  auto stage_tile = [&](int kt) {
+    const int rin = lane >> 3, pc = lane & 7;
+    char* dst = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int grp = wave + j * NW;  // 0..7: K pieces, 8..15: V pieces
+      if (grp < 2 * TK / 8) {
+        const bool isv = grp >= TK / 8;
+        const int row = (isv ? grp - TK / 8 : grp) * 8 + rin;        // key inside the tile
+        const int srow = min(kt * TK + row, S - 1);                   // padded keys read a valid row (masked below)
+        const int c = isv ? ((((pc >> 1) ^ ((row >> 1) & 3)) << 1) | (pc & 1)) : (pc ^ ((row >> 1) & 7));
+        const bf16* src = (isv ? Vg : Kg) + (long)srow * ld + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + grp * 1024), 16, 0, 0);
+      }
+    }
+  };
+  stage_tile(0);
+
+  const float kScale = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  const f32x2 c2 = {kScale, kScale};
+  float m = kNegInf, l = 0.f;  // running max of the raw scores / running sum, for query r (replicated over q4)
+  f32x4 o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt
+    __syncthreads();                                   // everyone's pieces; and tile kt-1 is no longer being read
+    if (kt + 1 < nkt) stage_tile(kt + 1);
+    if (!active) continue;
+    const char* Ks = smem + (kt & 1) * STAGE;
+    const char* Vs = Ks + TK * 128;
+    f32x4 sT[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + r) * 128 + (((4 * s + q4) ^ f) << 4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc, 0, 0, 0);
+      }
+      sT[t] = acc;
+    }
+    float mx = m;
+    const bool tail = (kt + 1) * TK > S;  // uniform: only the last tile can hold padded keys
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (tail) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kt * TK + t * 16 + 4 * q4 + e >= S) sT[t][e] = kNegInf;
+      }
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(sT[t][0]), "v"(sT[t][1]));
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(sT[t][2]), "v"(sT[t][3]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // >= m, finite from the first tile on (key 0 is never masked)
+    const float alpha = __builtin_amdgcn_exp2f((m - mx) * kScale);  // exp2(-inf) = 0 on the first tile
+    m = mx;
+    const f32x2 nm2 = {-mx * kScale, -mx * kScale};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x2 a = {sT[t][0], sT[t][1]}, b = {sT[t][2], sT[t][3]};
+      a = a * c2 + nm2;
+      b = b * c2 + nm2;
+      a = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+      b = f32x2{__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+      sum2 += a;
+      sum2 += b;
+      sT[t] = f32x4{a[0], a[1], b[0], b[1]};
+    }
+    float sum = sum2[0] + sum2[1];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    l = l * alpha + sum;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] *= alpha;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = static_cast<bf16>(sT[2 * ks][e]);
+        pf[4 + e] = static_cast<bf16>(sT[2 * ks + 1][e]);
+      }
+      const int key0 = ks * 32 + 4 * q4 + tq;
+      const int sw0 = (key0 >> 1) & 3, sw1 = ((key0 + 16) >> 1) & 3;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(Vs + key0 * 128 + ((n ^ sw0) << 5) + tp * 8));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(Vs + (key0 + 16) * 128 + ((n ^ sw1) << 5) + tp * 8));
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[n], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  const float inv = __builtin_amdgcn_rcpf(l);
+  char* patch = smem + OFF_O + wave * 2048;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    bf16x4 pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = static_cast<bf16>(o[n][e] * inv);
+    *reinterpret_cast<bf16x4*>(patch + r * 128 + (((n * 4 + q4) ^ ((r & 7) << 1)) << 3)) = pk;
+  }
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = hh * 8 + (lane >> 3), ch = lane & 7;
+    const bf16x8 val = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((2 * ch) ^ ((row & 7) << 1)) << 3));
+    const int qo = qt * 16 + row;
+    if (qo < S) *reinterpret_cast<bf16x8*>(out + ((long)seq * S + qo) * D + h * 64 + ch * 8) = val;
+  }
+}
+
+// f32 parity kernel: thread per query (256 queries per workgroup), K/V rows broadcast from LDS in chunks of `kc` keys
+// (any sequence length; one chunk up to 256 keys), online softmax in key order.
 template <bool CAUSAL>
 __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
-                                                       int heads) {
+                                                       int heads, int kc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Ks = reinterpret_cast<float*>(smem);
-  float* Vs = Ks + S * 64;
+  float* Vs = Ks + kc * 64;
   const int tid = threadIdx.x;
   const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
   const int D = heads * 64;
   const long ld = 3L * D;
   const float* base = qkv + (long)seq * S * ld + h * 64;
-  for (int idx = tid; idx < S * 16; idx += 256) {
-    const int key = idx >> 4, c = (idx & 15) * 4;
-    *reinterpret_cast<f32x4*>(Ks + key * 64 + c) = *reinterpret_cast<const f32x4*>(base + D + key * ld + c);
-    *reinterpret_cast<f32x4*>(Vs + key * 64 + c) = *reinterpret_cast<const f32x4*>(base + 2 * D + key * ld + c);
-  }
-  __syncthreads();
-  for (int query = tid; query < S; query += 256) {
-    float qv[64], o[64];
+  const int query = blockIdx.y * 256 + tid;
+  const bool valid = query < S;
+  float qv[64], o[64];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(base + query * ld + c * 4);
+  for (int c = 0; c < 16; ++c) {
+    const f32x4 t = valid ? *reinterpret_cast<const f32x4*>(base + query * ld + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        qv[c * 4 + e] = t[e] * 0.125f;
-        o[c * 4 + e] = 0.f;
-      }
+    for (int e = 0; e < 4; ++e) {
+      qv[c * 4 + e] = t[e] * 0.125f;
+      o[c * 4 + e] = 0.f;
     }
-    float m = kNegInf, l = 0.f;
-    const int kend = CAUSAL ? query + 1 : S;
-    for (int key = 0; key < kend; ++key) {
+  }
+  float m = kNegInf, l = 0.f;
+  const int kend = CAUSAL ? query + 1 : S;
+  for (int k0 = 0; k0 < S; k0 += kc) {
+    const int kn = min(kc, S - k0);
+    __syncthreads();  // the previous chunk is no longer being read
+    for (int idx = tid; idx < kn * 16; idx += 256) {
+      const int key = idx >> 4, c = (idx & 15) * 4;
+      *reinterpret_cast<f32x4*>(Ks + key * 64 + c) = *reinterpret_cast<const f32x4*>(base + D + (k0 + key) * ld + c);
+      *reinterpret_cast<f32x4*>(Vs + key * 64 + c) = *reinterpret_cast<const f32x4*>(base + 2 * D + (k0 + key) * ld + c);
+    }
+    __syncthreads();
+    const int stop = valid ? min(kn, kend - k0) : 0;
+    for (int key = 0; key < stop; ++key) {
       const float* kr = Ks + key * 64;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -396,10 +560,10 @@ __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__
         s2 = fmaf(qv[c * 4 + 2], kv[2], s2);
         s3 = fmaf(qv[c * 4 + 3], kv[3], s3);
       }
-      const float s = (s0 + s1) + (s2 + s3);
-      const float mn = fmaxf(m, s);
+      const float sc = (s0 + s1) + (s2 + s3);
+      const float mn = fmaxf(m, sc);
       const float a = expf(m - mn);  // exp(-inf) = 0 on the first key
-      const float p = expf(s - mn);
+      const float p = expf(sc - mn);
       l = l * a + p;
       m = mn;
       const float* vr = Vs + key * 64;
@@ -410,15 +574,16 @@ __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__
         for (int e = 0; e < 4; ++e) o[c * 4 + e] = fmaf(p, vv[e], o[c * 4 + e] * a);
       }
     }
-    const float inv = 1.f / l;
-    float* orow = out + ((long)seq * S + query) * D + h * 64;
+  }
+  if (!valid) return;
+  const float inv = 1.f / l;
+  float* orow = out + ((long)seq * S + query) * D + h * 64;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      f32x4 t;
+  for (int c = 0; c < 16; ++c) {
+    f32x4 t;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = o[c * 4 + e] * inv;
-      *reinterpret_cast<f32x4*>(orow + c * 4) = t;
-    }
+    for (int e = 0; e < 4; ++e) t[e] = o[c * 4 + e] * inv;
+    *reinterpret_cast<f32x4*>(orow + c * 4) = t;
   }
 }
 
@@ -447,6 +612,32 @@ int launch_bf16_v2(const void* qkv, void* out, int n_seq, int S, int heads, int 
   return launch_bf16_v2_variant<NKT, NWAVES, false, 0>(qkv, out, n_seq, S, heads, st);
 }
 
+template <int NW>
+int launch_bf16_flash_nw(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
+  constexpr int lds = 2 * 2 * 64 * 128 + NW * 2048;
+  const int nqb = ((S + 15) / 16 + NW - 1) / NW;
+  const long blocks = (long)n_seq * heads * nqb;
+  if (blocks > 0x7fffffffL) return fail(FC_EINVAL, "attention(bf16): grid of %ld workgroups", blocks);
+  hipLaunchKernelGGL((attn_bf16_flash_kernel<NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, st, (const bf16*)qkv,
+                     (bf16*)out, S, heads, nqb);
+  FC_CHECK_LAUNCH("attention(bf16 flash)");
+  return FC_OK;
+}
+
+// waves per workgroup = 16-query tiles per query block: the choice that wastes the fewest padded tiles (257 tokens =
+// 17 tiles -> 3 blocks of 6; 577 tokens = 37 tiles -> 5 blocks of 8 would pad 3, 7 blocks of 6 pads 5, 10 of 4 pads 3)
+int launch_bf16_flash(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
+  const int nqt = (S + 15) / 16;
+  int best = 8, waste = 1 << 30;
+  for (int nw : {8, 6, 4}) {
+    const int w = (nqt + nw - 1) / nw * nw - nqt;
+    if (w < waste) { waste = w; best = nw; }
+  }
+  if (best == 8) return launch_bf16_flash_nw<8>(qkv, out, n_seq, S, heads, st);
+  if (best == 6) return launch_bf16_flash_nw<6>(qkv, out, n_seq, S, heads, st);
+  return launch_bf16_flash_nw<4>(qkv, out, n_seq, S, heads, st);
+}
+
 template <int NKT>
 int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
   constexpr int NK = NKT * 16;
@@ -473,29 +664,29 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
       if (S <= 32) return launch_bf16_v2<2, 2>(qkv, out, n_seq, S, heads, causal, stream);
       if (S <= 96) return launch_bf16_v2<6, 5>(qkv, out, n_seq, S, heads, causal, stream);
       if (S <= 224) return launch_bf16_v2<14, 7>(qkv, out, n_seq, S, heads, causal, stream);
-      return fail(FC_EINVAL, "attention(bf16): sequence length %d > 224 not supported", S);
+      if (causal) return fail(FC_EINVAL, "attention(bf16): causal attention over %d > 224 tokens is not supported", S);
+      return launch_bf16_flash(qkv, out, n_seq, S, heads, stream);
     }
     if (S <= 32) return launch_bf16<2>(qkv, out, n_seq, S, heads, causal, stream);
     if (S <= 96) return launch_bf16<6>(qkv, out, n_seq, S, heads, causal, stream);
     if (S <= 224) return launch_bf16<14>(qkv, out, n_seq, S, heads, causal, stream);
     return fail(FC_EINVAL, "attention(bf16): sequence length %d > 224 not supported", S);
   }
-  const int lds = S * 64 * 4 * 2;
-  if (lds > 160 * 1024) return fail(FC_EINVAL, "attention(f32): sequence length %d does not fit LDS", S);
+  const int kc = std::min(S, 256), lds = kc * 64 * 4 * 2;
   auto k0 = attn_f32_kernel<false>;
   auto k1 = attn_f32_kernel<true>;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
       return fail(FC_ELAUNCH, "attention(f32): cannot raise dynamic LDS");
     configured = true;
   }
-  const dim3 grid(n_seq * heads), block(256);
+  const dim3 grid(n_seq * heads, (S + 255) / 256), block(256);
   if (causal)
-    hipLaunchKernelGGL(k1, grid, block, lds, stream, (const float*)qkv, (float*)out, S, heads);
+    hipLaunchKernelGGL(k1, grid, block, lds, stream, (const float*)qkv, (float*)out, S, heads, kc);
   else
-    hipLaunchKernelGGL(k0, grid, block, lds, stream, (const float*)qkv, (float*)out, S, heads);
+    hipLaunchKernelGGL(k0, grid, block, lds, stream, (const float*)qkv, (float*)out, S, heads, kc);
   FC_CHECK_LAUNCH("attention(f32)");
   return FC_OK;
 }

@@ -76,7 +76,9 @@ int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stri
                          int write_x, int delta_compact, hipStream_t stream);
 // dst[i] = src row (idx ? idx[i] : i * step), rows of row_bytes bytes (multiple of 16)
 int launch_gather_rows(const void* src, const int* idx, long step, void* dst, int n, int row_bytes, hipStream_t stream);
-int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream);
+int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, int Kp,
+                  hipStream_t stream);
+int launch_convert_rows(const float* in, void* out, int out_kind, long rows, int K, int Kp, hipStream_t stream);
 // uint8 [n,H,W,3] -> f32 NCHW [n,3,R,R]: /255, bicubic resize (shorter side R), centre crop, mean/std (host arrays)
 int launch_preprocess_u8(const unsigned char* frames, float* out, int n, int H, int W, int R, const float* mean3,
                          const float* std3, hipStream_t stream);

@@ -222,6 +222,39 @@ __global__ void __launch_bounds__(256) im2col_kernel(const float* __restrict__ f
   }
 }
 
+// Same mapping for ANY patch size (14: 3 * 196 = 588 columns) and a row stride Kp >= 3 p^2 padded to the GEMM's K
+// granule: one thread per output element, columns k >= 3 p^2 are written as zeros (the packed conv weight is padded
+// with zeros as well, so the extra K steps add exact zeros).
+template <typename OutT>
+__global__ void __launch_bounds__(256) im2col_padded_kernel(const float* __restrict__ frames, OutT* __restrict__ out,
+                                                            int n, int R, int p, int Kp) {
+  const int g = R / p, K = 3 * p * p;
+  const long total = (long)n * g * g * Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const long row = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (p * p), rem = k - c * p * p, py = rem / p, px = rem - py * p;
+      const int gx = (int)(row % g), gy = (int)((row / g) % g);
+      const long img = row / ((long)g * g);
+      v = frames[((img * 3 + c) * R + gy * p + py) * (long)R + gx * p + px];
+    }
+    put<OutT>(out + i, v);
+  }
+}
+
+// out[r, 0..Kp) = in[r, 0..K) followed by zeros (packing of conv1.weight when 3 p^2 is not a multiple of the K granule)
+template <typename OutT>
+__global__ void __launch_bounds__(256) convert_rows_kernel(const float* __restrict__ in, OutT* __restrict__ out,
+                                                           long rows, int K, int Kp) {
+  const long total = rows * Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    put<OutT>(out + i, k < K ? in[(i / Kp) * K + k] : 0.f);
+  }
+}
+
 // ---------------------------------------------------------------------------------- eval preprocessing (N1)
 // uint8 frames [n, H, W, 3] -> fp32 NCHW [n, 3, R, R]: /255, bicubic resize of the shorter side to R (PyTorch
 // semantics: A = -0.75, half-pixel centres, border taps clamped), centre crop, (x - mean) / std.  One thread per output
@@ -451,15 +484,40 @@ int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stri
                                                    D, write_x, delta_compact, stream);
 }
 
-int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, hipStream_t stream) {
+int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, int Kp,
+                  hipStream_t stream) {
   if (n <= 0) return FC_OK;
-  if (res % patch || patch % 4) return fail(FC_EINVAL, "im2col: resolution %d / patch %d", res, patch);
-  const int blocks = flat_blocks((size_t)n * 3 * res * res / 4);
-  if (out_kind == 1)
-    hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, frames, (bf16*)patches, n, res, patch);
-  else
-    hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, stream, frames, (float*)patches, n, res, patch);
+  const int K = 3 * patch * patch;
+  if (patch <= 0 || res % patch || Kp < K) return fail(FC_EINVAL, "im2col: resolution %d / patch %d / Kp %d", res, patch, Kp);
+  if (patch % 4 == 0 && Kp == K) {  // 16-byte moves of 4 consecutive pixels of a patch row
+    const int blocks = flat_blocks((size_t)n * 3 * res * res / 4);
+    if (out_kind == 1)
+      hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, frames, (bf16*)patches, n, res, patch);
+    else
+      hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, stream, frames, (float*)patches, n, res, patch);
+  } else {
+    const int g = res / patch;
+    const int blocks = flat_blocks((size_t)n * g * g * Kp);
+    if (out_kind == 1)
+      hipLaunchKernelGGL(im2col_padded_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, frames, (bf16*)patches, n, res,
+                         patch, Kp);
+    else
+      hipLaunchKernelGGL(im2col_padded_kernel<float>, dim3(blocks), dim3(256), 0, stream, frames, (float*)patches, n,
+                         res, patch, Kp);
+  }
   FC_CHECK_LAUNCH("im2col");
+  return FC_OK;
+}
+
+int launch_convert_rows(const float* in, void* out, int out_kind, long rows, int K, int Kp, hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  if (Kp < K) return fail(FC_EINVAL, "convert_rows: Kp %d < K %d", Kp, K);
+  const int blocks = flat_blocks((size_t)rows * Kp);
+  if (out_kind == 1)
+    hipLaunchKernelGGL(convert_rows_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, in, (bf16*)out, rows, K, Kp);
+  else
+    hipLaunchKernelGGL(convert_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, in, (float*)out, rows, K, Kp);
+  FC_CHECK_LAUNCH("convert_rows");
   return FC_OK;
 }
 

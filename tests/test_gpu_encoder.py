@@ -342,3 +342,40 @@ def test_pruned_last_block_is_bit_identical(vitb16_state_dict, precision):
     assert torch.equal(pruned.encode_text({"input_ids": ids}), full.encode_text({"input_ids": ids}))
     assert torch.equal(pruned.encode_text({"input_ids": torch.from_numpy(synth.make_text(7, d, 14, all_random=True)).to(DEV)}),
                        full.encode_text({"input_ids": torch.from_numpy(synth.make_text(7, d, 14, all_random=True)).to(DEV)}))
+
+
+# The reference's other CLIP ViT configs (config/encoder/clip_vit_b_32.yaml, clip_vit_l_14.yaml, clip_vit_l_14_336px.yaml)
+# go through the same ClipVideoTextEncoder.  Shrunk stand-ins with their awkward geometry: patch 14 (3*14*14 = 588
+# columns: not a multiple of the GEMM's K tile -> zero-padded patch-embed), 257 and 577 tokens (> 224: the streaming
+# attention kernel), width 1024 / 16 heads, a 768-wide text tower; patch 32 with 50 tokens.
+_OTHER_VITS = {
+    "L14-like": synth.ClipDims(embed_dim=768, image_resolution=224, vision_layers=2, vision_width=1024,
+                               vision_patch_size=14, context_length=77, vocab_size=2048, transformer_width=768,
+                               transformer_heads=12, transformer_layers=2),
+    "L14@336-like": synth.ClipDims(embed_dim=256, image_resolution=336, vision_layers=1, vision_width=256,
+                                   vision_patch_size=14, context_length=16, vocab_size=1024, transformer_width=128,
+                                   transformer_heads=2, transformer_layers=1),
+    "B32-like": synth.ClipDims(embed_dim=512, image_resolution=224, vision_layers=2, vision_width=768,
+                               vision_patch_size=32, context_length=77, vocab_size=2048, transformer_width=512,
+                               transformer_heads=8, transformer_layers=2),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(_OTHER_VITS))
+def test_other_clip_vit_geometries_match_oracle(tag):
+    d = _OTHER_VITS[tag]
+    sd = synth.make_state_dict(d, seed=7)
+    video = synth.make_video(3, 2, d, seed=11)
+    ids = synth.make_text(5, d, seed=12)
+    ref_v = O.encode_video(O.to_torch(sd), torch.from_numpy(video)).numpy()
+    ref_t = O.encode_text(O.to_torch(sd), {"input_ids": torch.from_numpy(ids)}).numpy()
+    for precision in ("fp32", "bf16"):
+        enc = _encoder(sd, precision)
+        enc.num_frames = 2
+        got_v = enc.encode_video(torch.from_numpy(video).to(DEV)).cpu().numpy()
+        got_t = enc.encode_text({"input_ids": torch.from_numpy(ids).to(DEV)}).cpu().numpy()
+        if precision == "fp32":
+            assert np.abs(got_v - ref_v).max() < F32_TOL and np.abs(got_t - ref_t).max() < F32_TOL
+        else:
+            assert np.abs(got_v - ref_v).max() < 2e-2 and np.abs(got_t - ref_t).max() < 2e-2
+            assert _signal_rel_err(got_t, ref_t) < 0.15

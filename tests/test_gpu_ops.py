@@ -112,7 +112,11 @@ def _attention_ref(qkv, n, S, heads, causal):
 
 
 @pytest.mark.parametrize("n,S,heads,causal", [(3, 197, 12, False), (5, 77, 8, True), (2, 17, 4, False),
-                                              (4, 16, 2, True), (1, 224, 1, False), (2, 33, 2, True)])
+                                              (4, 16, 2, True), (1, 224, 1, False), (2, 33, 2, True),
+                                              # > 224 tokens: the streaming kernel (ViT-L/14: 257, @336px: 577) and
+                                              # tile-boundary cases of its 64-key ring / 16-query tiles
+                                              (2, 257, 16, False), (1, 577, 3, False), (2, 225, 1, False),
+                                              (1, 256, 2, False), (1, 320, 1, False), (1, 321, 2, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention(n, S, heads, causal, dtype):
     qkv = _rand(n * S, 3 * heads * 64, seed=S)
