@@ -280,6 +280,11 @@ constexpr int piece_slot(int sched, int idx) {
     case 6: return idx < 2 ? -1 : (idx - 2) / 2;     // 2 in the hand-over, 2 after each of groups 0..2
     case 7: return idx / 2;                          // 2 after each of groups 0..3
     case 8: return idx < 4 ? 1 : 0;                  // group 0: W, group 1: A
+    case 9: return 0;                                // all 8 after group 0
+    case 10: return idx < 4 ? 2 : 0;                 // group 0: W, group 2: A
+    case 11: return idx < 4 ? 2 + idx / 2 : (idx - 4) / 2;  // W over groups 0, 1; A over groups 2, 3
+    case 12: return idx < 4 ? 0 : -1;                // W in the hand-over, A after group 0
+    case 13: return idx < 4 ? 2 : 1;                 // group 1: W, group 2: A
     default: return -1;                              // everything in the hand-over
   }
 }
