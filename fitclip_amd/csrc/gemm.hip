@@ -57,10 +57,12 @@ int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
   return FC_OK;
 }
 
-// LDS-DMA issue schedule (gemm_kernel.h: piece_slot), measured with tools/gemm_lab (profiles/r01_lab17_sched.log):
-// short-K GEMMs whose activation panel is re-read from L2 by 9-12 column tiles (QKV, out_proj, c_fc) gain 6-8 % from
-// spreading all pieces over the first two MFMA groups of the next K-step (8); the K = 3072 c_proj streams its
-// activations from HBM and wants them requested as early as possible (2: activations in the hand-over, weights spread).
+// LDS-DMA issue schedule (gemm_kernel.h: piece_slot).  Lab (tools/gemm_lab, profiles/r01_lab17_sched.log): the K = 768
+// shapes gain 6-8 % from spreading all pieces over the first two MFMA groups of the next K-step (8), the K = 3072
+// c_proj, which streams its activations from HBM, 4 % from requesting them early (2: activations in the hand-over,
+// weights after group 0).  In situ (kernel traces of bench.py per schedule, tools/sched_ab.sh,
+// profiles/r01_sched_in_situ.txt) only c_fc keeps the gain of 8 (433 vs 448 / 462 us for 2 / 0); QKV is indifferent
+// between 2 and 8, out_proj and c_proj are fastest with 2.  Hence: 8 for the QuickGELU GEMM, 2 otherwise.
 // FITCLIP_GEMM_SCHED=0|2|8 overrides (A/B runs); the result does not depend on the schedule.
 template <typename T, int EPI>
 int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
@@ -68,7 +70,7 @@ int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
     const char* e = getenv("FITCLIP_GEMM_SCHED");
     return e ? atoi(e) : -1;
   }();
-  const int sched = forced >= 0 ? forced : ((size_t)a.K * sizeof(T) > 2048 ? 2 : 8);
+  const int sched = forced >= 0 ? forced : (EPI == EPI_GELU_T ? 8 : 2);
   switch (sched) {
     case 2: return launch_pipelined_sched<T, EPI, 2>(a, stream);
     case 8: return launch_pipelined_sched<T, EPI, 8>(a, stream);

@@ -1,10 +1,13 @@
 #!/usr/bin/env python
-"""Per-shape summary of a rocprofv3 --kernel-trace CSV of bench.py: labels the block GEMMs by their position in the
-layer sequence (QKV, out_proj | c_fc | c_proj) and prints average durations / TFLOP/s per shape.
+"""Per-shape summary of a rocprofv3 --kernel-trace CSV of bench.py: labels the block GEMMs of the VISUAL tower by their
+position in the layer sequence (QKV, out_proj | c_fc | c_proj), splits off the much shorter text-tower launches of the
+same kernels by duration, and prints average durations / TFLOP/s per shape plus the dispatch gaps (wall span of the
+trace minus the summed kernel time).
 
     python tools/trace_summary.py <..._kernel_trace.csv> [frames_per_chunk]
 """
 import csv
+import statistics
 import sys
 from collections import defaultdict
 
@@ -14,19 +17,14 @@ def main():
     chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    agg = defaultdict(lambda: [0.0, 0])
-    seq = 0
     M = chunk * 197
     shapes = {"qkv": (2304, 768), "out_proj": (768, 768), "c_fc": (3072, 768), "c_proj": (768, 3072)}
-    total = 0.0
+    labelled = []
     for r in rows:
         name = r["Kernel_Name"]
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        total += dur
-        wg = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else 0
-        if "gemm_pipelined_kernel" in name and "Li256ELi256ELi2ELi4ELi0E" in name and "DF16b" in name:
-            label = ("qkv", "out_proj", "c_proj")[seq % 3]
-            seq += 1
+        if "gemm_pipelined_kernel" in name and "DF16b" in name and "Li256ELi256ELi2ELi4ELi0E" in name:
+            label = "bias_gemm"
         elif "gemm_pipelined_kernel" in name and "Li256ELi256ELi2ELi4ELi1E" in name:
             label = "c_fc"
         elif "attn_" in name:
@@ -39,15 +37,35 @@ def main():
             label = "gemm(other)"
         else:
             label = "other"
-        agg[label][0] += dur
-        agg[label][1] += 1
-    print(f"total kernel time {total / 1e3:.2f} ms over {len(rows)} dispatches")
-    for k, (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        labelled.append([label, dur])
+    # visual-tower launches of the pipelined GEMMs run for > 80 us at chunk >= 256 frames; the text tower's for < 60 us
+    cut = 70.0
+    seq = 0
+    for item in labelled:
+        if item[0] == "bias_gemm":
+            if item[1] < cut:
+                item[0] = "text gemm"
+            else:
+                item[0] = ("qkv", "out_proj", "c_proj")[seq % 3]
+                seq += 1
+        elif item[0] == "c_fc" and item[1] < cut:
+            item[0] = "text gemm"
+        elif item[0] in ("attention", "add_layernorm") and item[1] < 40.0:
+            item[0] = "text " + item[0]
+    agg = defaultdict(list)
+    for label, dur in labelled:
+        agg[label].append(dur)
+    total = sum(d for _, d in labelled)
+    span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3
+    print(f"total kernel time {total / 1e3:.2f} ms over {len(rows)} dispatches; trace span {span / 1e3:.2f} ms "
+          f"(includes host-side setup between steps)")
+    for k, durs in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        us, n = sum(durs), len(durs)
         extra = ""
         if k in shapes:
             N, K = shapes[k]
-            extra = f"  (if M={M}: {2.0 * M * N * K / (us / n * 1e-6) / 1e12:7.1f} TF/s)"
-        print(f"{k:14s} n={n:5d} avg={us / n:9.1f} us total={us / 1e3:8.2f} ms {100 * us / total:5.1f}%{extra}")
+            extra = f"  (M={M}: {2.0 * M * N * K / (us / n * 1e-6) / 1e12:7.1f} TF/s avg, median {statistics.median(durs):.1f} us)"
+        print(f"{k:18s} n={n:5d} avg={us / n:9.1f} us total={us / 1e3:8.2f} ms {100 * us / total:5.1f}%{extra}")
 
 
 if __name__ == "__main__":
