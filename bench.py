@@ -78,7 +78,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--chunk-frames", type=int, default=0)
     ap.add_argument("--gemm-tile", type=int, default=0)
-    ap.add_argument("--cpu-sample-clips", type=int, default=4)
+    ap.add_argument("--cpu-sample-clips", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prune-last-block", action="store_true",
                     help="opt-in: only the pooled rows go through the MLP of the last block (identical embeddings)")
