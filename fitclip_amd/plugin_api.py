@@ -1,93 +1,102 @@
-"""The encoder plugin contract of the reference, restated (interface only).
+"""The encoder plugin contract of the reference, as a table.
 
-Mirrors `aligner/encoder/video_encoder.py:14-63` and `aligner/encoder/video_text_encoder.py:15-31`: the Lightning
-modules call `encoder(video=..., text=...)`, the data modules call the tokenizer / transform / frame-sampler factories
-and `should_pad_batch`.  Same method names, argument meaning and error behaviour (`NotImplementedError` for abstract
-methods), so an encoder written against the reference ABC and one written against this one are interchangeable.
+The reference wires its Lightning modules and data modules to an encoder through two small abstract classes
+(`aligner/encoder/video_encoder.py:14-52`, `aligner/encoder/video_text_encoder.py:15-31`).  What matters for a drop-in
+is only WHICH members are called by whom and what they mean, so the contract is written down once, as data
+(`VIDEO_CONTRACT`, `TEXT_CONTRACT`: member -> meaning and caller), and the two base classes are generated from it:
+every contract member raises `NotImplementedError` until a subclass defines it (the reference's behaviour for an
+abstract member that was not overridden), `forward` dispatches to the `encode_*` members, and `missing_members()`
+tells a subclass author what is still open.  An encoder written against the reference classes satisfies these, and
+vice versa.
 """
 from __future__ import annotations
 
-from abc import abstractmethod
-from typing import Callable, Iterable, Iterator, Mapping, Optional, Tuple
+from typing import Callable, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
 
-from .samplers import FrameSampler
-
-TYPE_VIDEO_INPUT = torch.Tensor
+TYPE_VIDEO_INPUT = torch.Tensor                                     # f32 [B, F, 3, H, W], already transformed
+TYPE_TEXT_INPUT = Mapping[str, torch.Tensor]                        # {"input_ids": int [B, context_length]}
+TYPE_OUTPUT = Tuple[torch.Tensor, torch.Tensor]                     # (video f32 [B, E], text f32 [B, E])
 TYPE_TRANSFORM = Callable[[torch.Tensor], torch.Tensor]
-TYPE_TEXT_INPUT = Mapping[str, torch.Tensor]
-TYPE_OUTPUT = Tuple[torch.Tensor, torch.Tensor]
 TYPE_TOKENIZER = Callable[[Iterable[str]], Mapping[str, torch.Tensor]]
 
+# member -> (meaning, caller in the reference)
+VIDEO_CONTRACT: Dict[str, Tuple[str, str]] = {
+    "encode_video": ("video f32 [B, F, 3, H, W] -> one embedding per clip, f32 [B, E]",
+                     "video_text_module.py:41 via forward; video_text_classification.py:58"),
+    "get_train_frame_sampler": ("FrameSampler used for training clips", "data/video_data_module.py:40-55"),
+    "get_eval_frame_sampler": ("FrameSampler used for evaluation clips", "data/video_data_module.py:40-55"),
+    "get_train_transform": ("dtype -> callable turning uint8 frames [F, H, W, 3] into the model input (training)",
+                            "data/video_data_module.py:40-55"),
+    "get_eval_transform": ("dtype -> callable turning uint8 frames [F, H, W, 3] into the model input (evaluation)",
+                           "data/video_data_module.py:40-55"),
+    "to_bchw": ("a model-input tensor rearranged to [B, C, H, W]", "visualisation scripts"),
+    "denormalize_video_tensor": ("a transformed video tensor back to uint8 0-255", "visualisation scripts"),
+}
+TEXT_CONTRACT: Dict[str, Tuple[str, str]] = {
+    "encode_text": ("{'input_ids': int [B, L]} -> f32 [B, E]",
+                    "video_text_module.py:41 via forward; video_text_classification.py:52,89,116"),
+    "get_tokenizer": ("callable: iterable of str -> {'input_ids': ...}",
+                      "data/video_data_module.py:75-78; teacher_student.py:88,112"),
+    "decode_text": ("a batch of token ids back to an iterator of strings", "prediction dumps"),
+}
 
+
+def _unimplemented(name: str, meaning: str, caller: str):
+    def member(self, *args, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__} does not implement {name}(): {meaning}")
+
+    member.__name__ = member.__qualname__ = name
+    member.__doc__ = f"{meaning}.  Called from {caller}."
+    member._contract_placeholder = True
+    return member
+
+
+def _with_contract(contract: Mapping[str, Tuple[str, str]]):
+    def decorate(cls):
+        for name, (meaning, caller) in contract.items():
+            if name not in cls.__dict__:
+                setattr(cls, name, _unimplemented(name, meaning, caller))
+        return cls
+
+    return decorate
+
+
+@_with_contract(VIDEO_CONTRACT)
 class VideoEncoder(nn.Module):
-    @abstractmethod
-    def encode_video(self, video: TYPE_VIDEO_INPUT) -> torch.Tensor:
-        raise NotImplementedError
+    """Video-only half of the contract; calling the module encodes the video."""
 
     def forward(self, video: TYPE_VIDEO_INPUT) -> torch.Tensor:
         return self.encode_video(video)
 
-    @abstractmethod
-    def get_train_frame_sampler(self) -> FrameSampler:
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_eval_frame_sampler(self) -> FrameSampler:
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_train_transform(self, dtype: torch.dtype) -> TYPE_TRANSFORM:
-        raise NotImplementedError
-
-    @abstractmethod
-    def get_eval_transform(self, dtype: torch.dtype) -> TYPE_TRANSFORM:
-        raise NotImplementedError
-
     @property
     def should_pad_batch(self) -> bool:
-        raise NotImplementedError
+        """Whether the data module pads every clip of a batch to the same number of frames (data/video_data_module.py)."""
+        raise NotImplementedError(f"{type(self).__name__} does not define should_pad_batch")
 
-    @abstractmethod
-    def to_bchw(self, t: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError
-
-    @abstractmethod
-    def denormalize_video_tensor(self, video: TYPE_VIDEO_INPUT) -> torch.Tensor:
-        """Converts a transformed video tensor into an unsigned 8-bit integer tensor in the range 0-255."""
-        raise NotImplementedError
+    @classmethod
+    def missing_members(cls) -> List[str]:
+        """Contract members this class still inherits as placeholders."""
+        names: Sequence[str] = [*VIDEO_CONTRACT, *(TEXT_CONTRACT if issubclass(cls, VideoTextEncoder) else ())]
+        return [n for n in names if getattr(getattr(cls, n), "_contract_placeholder", False)]
 
 
+@_with_contract(TEXT_CONTRACT)
 class VideoTextEncoder(VideoEncoder):
-    @abstractmethod
-    def encode_text(self, text: TYPE_TEXT_INPUT) -> torch.Tensor:
-        raise NotImplementedError
+    """Both towers; calling the module returns `(encode_video(video), encode_text(text))`."""
 
-    def forward(self, video: TYPE_VIDEO_INPUT, text: TYPE_TEXT_INPUT) -> TYPE_OUTPUT:  # noqa
+    def forward(self, video: TYPE_VIDEO_INPUT, text: TYPE_TEXT_INPUT) -> TYPE_OUTPUT:  # noqa: the signature widens on purpose
         return self.encode_video(video), self.encode_text(text)
-
-    @abstractmethod
-    def get_tokenizer(self) -> TYPE_TOKENIZER:
-        raise NotImplementedError
-
-    @abstractmethod
-    def decode_text(self, text: TYPE_TEXT_INPUT) -> Iterator[str]:
-        """Decodes a batch of texts."""
-        raise NotImplementedError
 
 
 def float_standard_denormalize(video: TYPE_VIDEO_INPUT, mean: Optional[Tuple[float, float, float]] = None,
                                std: Optional[Tuple[float, float, float]] = None) -> torch.Tensor:
-    """Undo a per-channel (x - mean) / std normalisation and quantise to uint8 0-255.
+    """Undoes a per-channel `(x - mean) / std` and quantises to uint8 0-255.
 
-    Like the reference helper (`video_encoder.py:55-63`) it scales and shifts `video` IN PLACE before the cast."""
-    def per_channel(values: Tuple[float, float, float]) -> torch.Tensor:
-        return torch.as_tensor(values, dtype=video.dtype, device=video.device).reshape(-1, 1, 1)
-
-    if std is not None:
-        video.mul_(per_channel(std))
-    if mean is not None:
-        video.add_(per_channel(mean))
+    As with the reference helper (`video_encoder.py:55-63`) the scaling and shifting happen IN PLACE on `video`."""
+    for values, apply in ((std, video.mul_), (mean, video.add_)):
+        if values is not None:
+            apply(torch.as_tensor(values, dtype=video.dtype, device=video.device).reshape(-1, 1, 1))
     return video.mul(255).to(torch.uint8)

@@ -90,3 +90,36 @@ def test_product_fails_loudly_without_gpu():
     from fitclip_amd import ops
     with pytest.raises(_lib.FitclipHipError):
         ops.similarity(torch.zeros(4, 32), torch.zeros(4, 32))
+
+
+def test_plugin_contract_table_matches_the_reference_members():
+    """`aligner/encoder/video_encoder.py:14-52` + `video_text_encoder.py:15-31`: member names, forward dispatch and the
+    NotImplementedError behaviour of members a subclass leaves open."""
+    import torch
+
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+    from fitclip_amd.plugin_api import TEXT_CONTRACT, VIDEO_CONTRACT, VideoEncoder, VideoTextEncoder
+
+    assert set(VIDEO_CONTRACT) == {"encode_video", "get_train_frame_sampler", "get_eval_frame_sampler",
+                                   "get_train_transform", "get_eval_transform", "to_bchw", "denormalize_video_tensor"}
+    assert set(TEXT_CONTRACT) == {"encode_text", "get_tokenizer", "decode_text"}
+    assert ClipVideoTextEncoder.missing_members() == []  # the shipped encoder implements the whole contract
+
+    class VideoOnly(VideoEncoder):
+        def encode_video(self, video):
+            return video.flatten(1).sum(1, keepdim=True)
+
+    class Half(VideoTextEncoder):
+        def encode_video(self, video):
+            return video.flatten(1).sum(1, keepdim=True)
+
+    v = torch.ones(2, 1, 3, 2, 2)
+    assert VideoOnly()(v).shape == (2, 1)
+    assert "encode_video" not in VideoOnly.missing_members() and "encode_text" not in VideoOnly.missing_members()
+    assert "encode_text" in Half.missing_members()
+    with pytest.raises(NotImplementedError):
+        Half()(video=v, text={"input_ids": torch.zeros(2, 4, dtype=torch.long)})
+    with pytest.raises(NotImplementedError):
+        Half().should_pad_batch
+    with pytest.raises(NotImplementedError):
+        VideoOnly().get_eval_frame_sampler()
