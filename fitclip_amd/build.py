@@ -32,6 +32,47 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+# attention.hip loads the Q fragments with inline-asm `global_load_dwordx4` (so that hipcc does not drain vmcnt to 0
+# while LDS-DMA pieces are in flight) and hands the registers to the compiler at a counted `s_waitcnt vmcnt`.  Nothing
+# may read those registers in between -- hipcc cannot know that, so the generated ISA is checked after every compile.
+ASYNC_LOAD_AUDIT = {"attention.hip": ["attn_bf16_v2_kernel"]}
+
+
+def audit_async_loads(asm_path: Path, kernel: str) -> int:
+    """Raises if, in any instantiation of `kernel`, an instruction between the asm loads and the first s_waitcnt vmcnt
+    names a register those loads write.  Returns the number of instantiations checked."""
+    import re
+    text = asm_path.read_text()
+    checked = 0
+    for m in re.finditer(r"^(\S*%s\S*):\s*;" % re.escape(kernel), text, flags=re.M):
+        body = text[m.end():]
+        body = body[:body.find("s_endpgm")]
+        loaded, waiting = set(), False
+        for line in body.splitlines():
+            code = line.split(";")[0]
+            ld = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", code)
+            if ld:
+                loaded.update(range(int(ld.group(1)), int(ld.group(2)) + 1))
+                waiting = True
+                continue
+            if not waiting:
+                continue
+            if re.search(r"s_waitcnt vmcnt\(\d+\)", code):
+                break
+            used = set(int(x) for x in re.findall(r"\bv(\d+)\b", code))
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code):
+                used.update(range(int(a), int(b) + 1))
+            if used & loaded:
+                raise RuntimeError(f"{asm_path.name}: {m.group(1)} touches a register of an asynchronous load before "
+                                   f"its s_waitcnt: {line.strip()}")
+        if not loaded:
+            raise RuntimeError(f"{asm_path.name}: {m.group(1)}: no asynchronous loads found (audit out of date?)")
+        checked += 1
+    if checked == 0:
+        raise RuntimeError(f"{asm_path.name}: kernel {kernel} not found for the asynchronous-load audit")
+    return checked
+
+
 def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     objdir = CSRC / "build"
@@ -43,11 +84,17 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
         obj = objdir / (src.replace(".hip", ".o"))
         if force or _stale(obj, [CSRC / src, *HEADERS]):
             cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
-            if save_temps:
+            if save_temps or src in ASYNC_LOAD_AUDIT:
                 cmd += ["-save-temps=obj"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True, cwd=str(objdir))
+            for kernel in ASYNC_LOAD_AUDIT.get(src, []):
+                try:
+                    audit_async_loads(objdir / (src.replace(".hip", "") + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s"), kernel)
+                except Exception:
+                    obj.unlink(missing_ok=True)  # never link an object that failed the audit
+                    raise
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
