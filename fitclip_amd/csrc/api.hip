@@ -242,8 +242,15 @@ Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols) {
 // cfg.prune_last_block: the towers only read the pooled row of each sequence after the last block, so in the last block
 // everything after the attention (out_proj, LayerNorm 2, c_fc, c_proj: 72 % of a block's FLOPs) is only computed for
 // those rows.  Rows of a GEMM / LayerNorm are independent, so the pooled rows come out bit-identical.
+// Visual tower entry folded into the first LayerNorm of the first block (layernorm_pair_kernel): class embedding and
+// positional_embedding[0] for the CLS rows, ln_pre weights.
+struct TowerEntry {
+  const float *cls, *pos0, *pre_w, *pre_b;
+};
+
 int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal,
-               const float* fin_w, const float* fin_b, const int* pool_idx, long pool_step, hipStream_t st) {
+               const float* fin_w, const float* fin_b, const int* pool_idx, long pool_step, hipStream_t st,
+               const TowerEntry* entry = nullptr) {
   const int M = n_seq * S;
   const int kind = h->cfg.precision;
   const int esz = h->esz;
@@ -251,7 +258,10 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
   const long xs_pool = pool_idx ? w : pool_step * w;  // x row stride seen through the pooling index
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
-    if (l == 0) {
+    if (l == 0 && entry) {
+      FC_TRY(launch_layernorm_pair(s.x, entry->cls, entry->pos0, S, entry->pre_w, entry->pre_b, b.ln1_w, b.ln1_b, s.xn,
+                                   kind, M, w, st));
+    } else if (l == 0) {
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
@@ -446,11 +456,10 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     FC_TRY(launch_im2col(f, s.big, kind, cn, R, c.vision_patch_size, Kp, st));
     FC_TRY(gemm(h, EPI_PATCH_F32, s.big, h->conv_w, nullptr, s.x, h->w("visual.positional_embedding"), cn * P, vw, Kp,
                 vw, P, st));
-    FC_TRY(launch_cls_pos(s.x, h->w("visual.class_embedding"), h->w("visual.positional_embedding"), cn, T, vw, st));
-    FC_TRY(launch_layernorm(s.x, vw, nullptr, h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias"), s.x, vw, 0,
-                            cn * T, vw, st));
+    const TowerEntry entry{h->w("visual.class_embedding"), h->w("visual.positional_embedding"),
+                           h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias")};
     FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),
-                      h->w("visual.ln_post.bias"), nullptr, T, st));
+                      h->w("visual.ln_post.bias"), nullptr, T, st, &entry));
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }

@@ -71,6 +71,9 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
                      void* y, long y_stride, int out_kind, int rows, int D, hipStream_t stream);
 // v = x[r] + delta[d] (delta of element kind `kind`, as y); x[r] = v if write_x; y[i] = LN(v).  r = gather ? gather[i] : i;
 // d = delta_compact ? i : r.
+int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tokens, const float* g0, const float* b0,
+                          const float* g1, const float* b1, void* y, int out_kind, int rows, int D,
+                          hipStream_t stream);
 int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
                          int write_x, int delta_compact, hipStream_t stream);
@@ -82,7 +85,6 @@ int launch_convert_rows(const float* in, void* out, int out_kind, long rows, int
 // uint8 [n,H,W,3] -> f32 NCHW [n,3,R,R]: /255, bicubic resize (shorter side R), centre crop, mean/std (host arrays)
 int launch_preprocess_u8(const unsigned char* frames, float* out, int n, int H, int W, int R, const float* mean3,
                          const float* std3, hipStream_t stream);
-int launch_cls_pos(float* x, const float* cls, const float* pos, int n, int tokens, int D, hipStream_t stream);
 int launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int* eot, int n, int L,
                       int D, int vocab, hipStream_t stream);
 int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int frames, int dim, hipStream_t stream);

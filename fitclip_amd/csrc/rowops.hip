@@ -87,6 +87,82 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// Entry of the visual tower in ONE pass over the fp32 stream:  x[r] = LN_pre(row r)  (written back: it is the residual
+// stream) and  y[r] = LN_1(x[r])  of the first block, where row r is the patch-embed output, or class_embedding +
+// positional_embedding[0] for the first token of every image (the CLS row is never materialised before).  Same
+// arithmetic, in the same order, as cls_pos + layernorm(ln_pre) + layernorm(ln_1); one read of x instead of two and two
+// launches fewer (clip.model.VisionTransformer.forward: cat CLS, + pos, ln_pre, then the first block's ln_1).
+template <int D, typename OutT>
+__global__ void __launch_bounds__(256) layernorm_pair_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                             const float* __restrict__ pos0, int tokens,
+                                                             const float* __restrict__ g0, const float* __restrict__ b0,
+                                                             const float* __restrict__ g1, const float* __restrict__ b1,
+                                                             OutT* __restrict__ y, int rows) {
+  constexpr int V4 = D / 256, REM = (D % 256) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+    float* xr = x + (long)row * D;
+    const bool is_cls = row % tokens == 0;  // wave-uniform
+    f32x4 v[V4 > 0 ? V4 : 1];
+    float s[REM > 0 ? REM : 1];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      const int c = i * 256 + lane * 4;
+      v[i] = is_cls ? *reinterpret_cast<const f32x4*>(cls + c) + *reinterpret_cast<const f32x4*>(pos0 + c)
+                    : *reinterpret_cast<const f32x4*>(xr + c);
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      const int c = V4 * 256 + i * 64 + lane;
+      s[i] = is_cls ? cls[c] + pos0[c] : xr[c];
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float* gamma = pass ? g1 : g0;
+      const float* beta = pass ? b1 : b0;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < V4; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+      for (int i = 0; i < REM; ++i) sum += s[i];
+      const float mean = wave_sum(sum) * (1.f / D);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < V4; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[i][e] -= mean;
+          sq += v[i][e] * v[i][e];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < REM; ++i) {
+        s[i] -= mean;
+        sq += s[i] * s[i];
+      }
+      const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / D) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < V4; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] * rstd * g4[e] + b4[e];
+        if (pass == 0) *reinterpret_cast<f32x4*>(xr + c) = v[i];
+        else put4<OutT>(y + (long)row * D + c, v[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < REM; ++i) {
+        const int c = V4 * 256 + i * 64 + lane;
+        s[i] = s[i] * rstd * gamma[c] + beta[c];
+        if (pass == 0) xr[c] = s[i];
+        else put<OutT>(y + (long)row * D + c, s[i]);
+      }
+    }
+  }
+}
+
 // Fused residual add + LayerNorm:  v = x[r] + delta[r];  (x[r] = v);  y[i] = LN(v).  `delta` is the projection output
 // a GEMM just wrote (element type T, as y), so the residual update costs no extra pass over the fp32 stream and the
 // GEMM epilogue stays a pure store (reference: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x)), slip.py:382-385).
@@ -306,16 +382,6 @@ __global__ void __launch_bounds__(256) preprocess_u8_kernel(const unsigned char*
   }
 }
 
-__global__ void __launch_bounds__(256) cls_pos_kernel(float* __restrict__ x, const float* __restrict__ cls,
-                                                      const float* __restrict__ pos, int n, int tokens, int D) {
-  const long total = (long)n * D;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int d = (int)(i % D);
-    const long img = i / D;
-    x[img * tokens * D + d] = cls[d] + pos[d];
-  }
-}
-
 // ------------------------------------------------------------------------------------------- text embedding
 // x[n, l, :] = token_embedding[ids[n, l]] + positional_embedding[l]; eot[n] = n * L + argmax(ids[n, :]) (first
 // maximum, as torch.argmax; reference slip.py:469-470,478).  One block per text.
@@ -470,6 +536,35 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
                        : layernorm_dispatch<float>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
 }
 
+template <typename OutT>
+int layernorm_pair_dispatch(float* x, const float* cls, const float* pos0, int tokens, const float* g0, const float* b0,
+                            const float* g1, const float* b1, void* y, int rows, int D, hipStream_t st) {
+  const int blocks = min((rows + 3) / 4, kMaxBlocks);
+  OutT* yo = reinterpret_cast<OutT*>(y);
+  switch (D) {
+    case 128: hipLaunchKernelGGL((layernorm_pair_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
+    case 256: hipLaunchKernelGGL((layernorm_pair_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
+    case 512: hipLaunchKernelGGL((layernorm_pair_kernel<512, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
+    case 768: hipLaunchKernelGGL((layernorm_pair_kernel<768, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
+    case 1024: hipLaunchKernelGGL((layernorm_pair_kernel<1024, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
+    default: return fail(FC_EINVAL, "layernorm_pair: unsupported width %d", D);
+  }
+  FC_CHECK_LAUNCH("layernorm_pair");
+  return FC_OK;
+}
+
+int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tokens, const float* g0, const float* b0,
+                          const float* g1, const float* b1, void* y, int out_kind, int rows, int D,
+                          hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  if (tokens <= 0 ||
+      (((uintptr_t)x | (uintptr_t)cls | (uintptr_t)pos0 | (uintptr_t)g0 | (uintptr_t)b0 | (uintptr_t)g1 | (uintptr_t)b1 |
+        (uintptr_t)y) & 15))
+    return fail(FC_EINVAL, "layernorm_pair: operands must be 16-byte aligned");
+  return out_kind == 1 ? layernorm_pair_dispatch<bf16>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream)
+                       : layernorm_pair_dispatch<float>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
+}
+
 int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
                          int write_x, int delta_compact, hipStream_t stream) {
@@ -533,13 +628,6 @@ int launch_preprocess_u8(const unsigned char* frames, float* out, int n, int H, 
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(flat_blocks((size_t)n * R * R)), dim3(256), 0, stream, frames, out, n,
                      H, W, nh, nw, R, top, left, mean, inv);
   FC_CHECK_LAUNCH("preprocess_u8");
-  return FC_OK;
-}
-
-int launch_cls_pos(float* x, const float* cls, const float* pos, int n, int tokens, int D, hipStream_t stream) {
-  if (n <= 0) return FC_OK;
-  hipLaunchKernelGGL(cls_pos_kernel, dim3(flat_blocks((size_t)n * D)), dim3(256), 0, stream, x, cls, pos, n, tokens, D);
-  FC_CHECK_LAUNCH("cls_pos");
   return FC_OK;
 }
 
