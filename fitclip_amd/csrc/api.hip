@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <set>
 #include <memory>
 #include <vector>
 
@@ -23,6 +25,19 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   g_error = buf;
   return code;
+}
+
+hipError_t raise_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kernel})) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({dev, kernel});
+  return e;
 }
 
 namespace {

@@ -590,13 +590,9 @@ __global__ void __launch_bounds__(256) attn_f32_kernel(const float* __restrict__
 template <int NKT, int NWAVES, bool CAUSAL, int NFULL>
 int launch_bf16_v2_variant(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
   constexpr int lds = 2 * NKT * 16 * 128 + NWAVES * 2048;
-  static bool configured = false;
-  if (!configured && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)attn_bf16_v2_kernel<NKT, NWAVES, CAUSAL, NFULL>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail(FC_ELAUNCH, "attention(bf16): cannot raise dynamic LDS");
-    configured = true;
-  }
+  if (lds > 64 * 1024 &&
+      raise_dynamic_lds((const void*)attn_bf16_v2_kernel<NKT, NWAVES, CAUSAL, NFULL>, lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "attention(bf16): cannot raise dynamic LDS");
   hipLaunchKernelGGL((attn_bf16_v2_kernel<NKT, NWAVES, CAUSAL, NFULL>), dim3(n_seq * heads), dim3(NWAVES * 64), lds, st,
                      (const bf16*)qkv, (bf16*)out, S, heads);
   FC_CHECK_LAUNCH("attention(bf16 v2)");
@@ -675,13 +671,8 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
   const int kc = std::min(S, 256), lds = kc * 64 * 4 * 2;
   auto k0 = attn_f32_kernel<false>;
   auto k1 = attn_f32_kernel<true>;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-      return fail(FC_ELAUNCH, "attention(f32): cannot raise dynamic LDS");
-    configured = true;
-  }
+  if (raise_dynamic_lds((const void*)k0, 128 * 1024) != hipSuccess || raise_dynamic_lds((const void*)k1, 128 * 1024) != hipSuccess)
+    return fail(FC_ELAUNCH, "attention(f32): cannot raise dynamic LDS");
   const dim3 grid(n_seq * heads, (S + 255) / 256), block(256);
   if (causal)
     hipLaunchKernelGGL(k1, grid, block, lds, stream, (const float*)qkv, (float*)out, S, heads, kc);

@@ -23,6 +23,9 @@ enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
 
 void set_error(const std::string& msg);
 int fail(int code, const char* fmt, ...);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): the attribute belongs to the function on the
+// CURRENT device, and a process may hold handles on several devices.  Thread-safe.  Returns hipSuccess or the error.
+hipError_t raise_dynamic_lds(const void* kernel, int bytes);
 
 #define FC_CHECK_LAUNCH(what)                                                          \
   do {                                                                                 \

@@ -13,13 +13,8 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * ROWB;
   auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI>;
-  static bool configured = false;  // per instantiation; the attribute is per function, not per device state we mutate
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);
-    configured = true;
-  }
+  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(WM * WN * 64), lds, stream, a);
   FC_CHECK_LAUNCH("gemm");
@@ -44,13 +39,8 @@ int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
   constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 32 * (BN / WN) : 0) + 2048;
   auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, 0, 1, SCHED>;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);
-    configured = true;
-  }
+  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(std::min(tiles, num_cus())), dim3(WM * WN * 64), lds, stream, a);
   FC_CHECK_LAUNCH("gemm(pipelined)");
