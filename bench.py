@@ -253,6 +253,23 @@ def main() -> None:
         sig = float((ev_ref - ev_ref.mean(0, keepdim=True)).norm(dim=1).mean())
         result["parity_vs_oracle_on_sample"] = {"video_max_abs": dv, "text_max_abs": dt,
                                                 "video_signal_norm": sig}
+        # rank agreement of the k x k score matrices (random towers put every off-diagonal cosine near 0.99, so R@k is
+        # at chance level and decided at the 1e-3 level: report how far the orderings agree instead)
+        s_gpu = (et[:k].cpu().double() @ ev[:k].cpu().double().T)
+        s_ref = (et_ref.double() @ ev_ref.double().T)
+        top = min(10, k)
+        overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in
+                      zip(s_gpu.topk(top, dim=1).indices, s_ref.topk(top, dim=1).indices)) / float(top * k)
+
+        def rank_rows(m):
+            return m.argsort(dim=1).argsort(dim=1).double()
+
+        ra, rb = rank_rows(s_gpu), rank_rows(s_ref)
+        ra, rb = ra - ra.mean(1, keepdim=True), rb - rb.mean(1, keepdim=True)
+        spearman = float(((ra * rb).sum(1) / (ra.norm(dim=1) * rb.norm(dim=1))).mean())
+        result["rank_agreement_on_sample"] = {"top10_overlap": round(overlap, 4), "spearman_per_row_mean": round(spearman, 4),
+                                              "score_max_abs": float((s_gpu - s_ref).abs().max()),
+                                              "score_row_std_ref": float(s_ref.std(dim=1).mean())}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
