@@ -13,11 +13,16 @@ pairs/s = N * 256 / (max over ranks of the step time).
 
 The same JSON line carries
   * "roofline": the dominant kernel (the MFMA GEMM instantiation with the largest total time), its average launch
-    duration measured with hipEvent pairs recorded by the library around every GEMM launch on the stream the kernels
-    run on, inside the timed region; achieved = algorithmic FLOPs per launch / that duration; peak = dense MFMA peak of
-    the dtype (2.5 PFLOP/s bf16, 157.3 TFLOP/s fp32-input MFMA; MI355X_MICROARCH.md).
+    duration measured with hipEvent pairs recorded by the library on the stream the kernels run on, inside the timed
+    region (only that kernel is instrumented there: an event pair serialises dispatch for a few microseconds);
+    achieved = algorithmic FLOPs per launch / that duration; peak = dense MFMA peak of the dtype (2.5 PFLOP/s bf16,
+    157.3 TFLOP/s fp32-input MFMA; MI355X_MICROARCH.md); traffic = HBM bytes per launch from the PMC passes in
+    profiles/traffic_r01.json (tools/profile_round.sh).
+  * after the timed region, untimed: one fully instrumented step ("time_split", "roofline_all_gemms", and the check of
+    which kernel dominates) and K passes of the visual tower alone ("roofline_vit_forward").
   * "cpu_baseline": the CPU oracle (oracle/clip_oracle.py, kind "port") timed on this host's cores over a bounded
-    sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample.
+    sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample
+    ("parity_vs_oracle_on_sample") and the agreement of the two score-matrix orderings ("rank_agreement_on_sample").
 """
 from __future__ import annotations
 
@@ -158,6 +163,13 @@ def main() -> None:
     split_elapsed = time.perf_counter() - t1
     records = enc.model.profile_records()
     enc.model.profile(0)
+    # ViT forward alone: the visual tower + pooling over the same frames, uninstrumented, untimed part
+    fence()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.encode_video(video)
+    torch.cuda.synchronize()
+    vit_elapsed = time.perf_counter() - t2
 
     # ---- which kernel dominates, and the time split: from the fully instrumented extra step
     def aggregate(recs):
@@ -216,6 +228,10 @@ def main() -> None:
     whole_path = {"achieved": round(step_flops * args.steps / elapsed / 1e12, 2), "unit": "TFLOP/s",
                   "frac": round(step_flops * args.steps / elapsed / 1e12 / peak, 4)}
 
+    vit_tf = n_local * args.frames * GF_PER_FRAME * args.steps / vit_elapsed / 1e12
+    vit_forward = {"achieved": round(vit_tf, 2), "unit": "TFLOP/s", "frac": round(vit_tf / peak, 4),
+                   "ms_per_pass": round(vit_elapsed / args.steps * 1e3, 3),
+                   "frames": n_local * args.frames, "note": "rank-local encode_video only, after the timed region"}
     metrics = D.metrics_from_ranks(all_ranks.cpu().numpy())
     result = {
         "metric": "video-text pairs/sec (8-frame 224^2, 77-tok)", "value": round(n_total * args.steps / elapsed, 2),
@@ -227,6 +243,7 @@ def main() -> None:
                    "clips_per_gpu": n_local, "frames": args.frames, "weights": "random init (seed 42)", "prune_last_block": bool(args.prune_last_block),
                    "sharding": f"clips over {world} rank(s), one RCCL all-gather of embeddings"},
         "roofline": roofline, "roofline_all_gemms": all_gemms, "roofline_whole_path": whole_path,
+        "roofline_vit_forward": vit_forward,
         "time_split": {**{k: {"share_of_step_time": round(v[0] / (split_elapsed * 1e3), 4), "launches": v[1],
                               "avg_launch_ms": round(v[0] / max(1, v[1]), 4)} for k, v in other_ms.items()},
                        "gemm": {"share_of_step_time": all_gemms["share_of_step_time"]},
