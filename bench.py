@@ -263,7 +263,16 @@ def main() -> None:
             t0 = time.perf_counter()
             ev_ref, et_ref = O.forward(sd_t, v_cpu, {"input_ids": ids_cpu})
             cpu_s = time.perf_counter() - t0
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.lower().startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         result["cpu_baseline"] = {"value": round(k / cpu_s, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+                                  "cpu_model": cpu_model,
                                   "sample": f"{k} clips x {args.frames} frames + {k} texts of the same batch, "
                                             f"fp32 PyTorch oracle, {cores} threads, {cpu_s:.1f} s"}
         dv, dt = (ev[:k].cpu() - ev_ref).abs().max().item(), (et[:k].cpu() - et_ref).abs().max().item()
