@@ -1,9 +1,10 @@
 // GEMM lab: standalone timing / ablation harness for the MFMA GEMM kernels (tuning aid; not part of the library).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fitclip_amd/csrc tools/gemm_lab.hip -o gpurun_out/gemm_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fitclip_amd/csrc -I include -I tools tools/gemm_lab.hip -o tools/bin/gemm_lab
 //   ./gemm_lab [M] [reps]
 // For every (shape, variant): checks 8192 sampled outputs against a naive fp32 dot product of the same bf16 operands,
 // then times `reps` back-to-back launches with hipEvents on random (never zero-filled) operands.
 #include "gemm_kernel.h"
+#include "gemm_deep_lab.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -97,6 +98,19 @@ void launch_pipelined(const GemmArgs& a, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int cap = 256 * (BM * BN >= 256 * 256 ? 1 : 2);
   hipLaunchKernelGGL(kern, dim3(tiles < cap ? tiles : cap), dim3(WM * WN * 64), lds, st, a);
+}
+
+template <int EPI, int ABL>
+void launch_deep(const GemmArgs& a, hipStream_t st) {
+  constexpr int lds = 4 * 512 * 64 + 8 * 2048 + 2048;
+  auto kern = gemm_deep_kernel<EPI, ABL>;
+  static bool configured = false;
+  if (!configured) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
 }
 
 #include "gemm_lab_variants.inc"
