@@ -284,6 +284,40 @@ def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_tex
     assert ranks.cpu().tolist() == want.tolist()
 
 
+def test_teacher_student_full_size_by_invariance(vitb16_state_dict):
+    """BASELINE configs[4] at full size: teacher + student ViT-B/16 forward over 512 clips x 8 frames and the KD / NCE
+    similarity losses on the 512 x 512 score matrices.  The oracle cannot run this size, so: (i) the batch is built
+    from 4 base clips / 8 base captions whose embeddings are computed alone (batch invariance, bit-exact); (ii) the
+    device losses equal the reference formulas (`aligner/loss.py:13-39`, `teacher_student.py:150-159`) evaluated in
+    float64 on the CPU from the SAME device embeddings; (iii) distilling a model into itself costs nothing."""
+    d = synth.VIT_B_16
+    n, f = 512, 8
+    student_sd = synth.perturbed_state_dict(vitb16_state_dict, d, seed=5, rel=0.05)
+    student, teacher = _encoder(student_sd, "bf16"), _encoder(vitb16_state_dict, "bf16")
+    student.num_frames = teacher.num_frames = f
+    base_v = torch.from_numpy(synth.make_video(4, f, d, seed=31)).to(DEV)
+    base_t = torch.from_numpy(synth.make_text(8, d, seed=31)).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    pick_v, pick_t = torch.randint(0, 4, (n,), generator=gen).to(DEV), torch.randint(0, 8, (n,), generator=gen).to(DEV)
+    batch = {"video_student": base_v[pick_v], "text_student": {"input_ids": base_t[pick_t]},
+             "video_teacher": base_v[pick_v], "text_teacher": {"input_ids": base_t[pick_t]}}
+    module = TeacherStudentModule(student, teacher, init_temperature=0.05)
+    (sv, stx), (tv, ttx) = out = module.step(batch)
+    for enc, v, t in ((student, sv, stx), (teacher, tv, ttx)):
+        assert torch.equal(v, enc.encode_video(base_v)[pick_v]) and torch.equal(t, enc.encode_text({"input_ids": base_t})[pick_t])
+    scale = 1 / 0.05
+    kd = float(module.dataset_step_end(out, labeled=False))
+    nce = float(module.dataset_step_end(out, labeled=True))
+    s64 = scale * (sv.double().cpu() @ stx.double().cpu().T)
+    t64 = scale * (tv.double().cpu() @ ttx.double().cpu().T)
+    want_kd = float(O.teacher_student_nce_loss(s64, t64)) * scale ** 2
+    want_nce = float(O.nce_loss(s64))
+    assert abs(kd - want_kd) <= 2e-4 * max(1.0, abs(want_kd)), (kd, want_kd)
+    assert abs(nce - want_nce) <= 2e-4 * max(1.0, abs(want_nce)), (nce, want_nce)
+    self_distilled = TeacherStudentModule(teacher, teacher, init_temperature=0.05)
+    assert abs(float(self_distilled.dataset_step_end(self_distilled.step(batch), labeled=False))) < 1e-6
+
+
 def test_wise_full_size_is_bit_exact(vitb16_state_dict):
     """WiSE over all 149.6 M parameters of ViT-B/16 (BASELINE configs[2]): bit-identical to the reference expression
     `(1 - w) * p1 + w * p2` evaluated by torch on the CPU."""
