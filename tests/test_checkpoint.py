@@ -132,3 +132,22 @@ def test_retrieval_module_ignores_teacher_keys_only():
     # the distillation module itself does NOT ignore them: a plain checkpoint lacks its teacher
     with pytest.raises(RuntimeError, match="Missing key"):
         TeacherStudentModule(_encoder(8), _encoder(9)).load_state_dict(plain.state_dict())
+
+
+def test_prepare_tools(tmp_path):
+    """`prepare-clip` (bare state dict + NaN logit_scale) and `prepare` (checkpoint kept, state_dict stripped):
+    scripts/prepare_trained_clip_checkpoint_for_evaluation.py, scripts/prepare_trained_checkpoint_for_evaluation.py."""
+    student, teacher = _encoder(11), _encoder(12)
+    path = tmp_path / "ts.ckpt"
+    C.save_checkpoint(TeacherStudentModule(student, teacher), path, epoch=7, optimizer_states=["opaque"])
+    out1, out2 = tmp_path / "clip.pt", tmp_path / "stripped.ckpt"
+    C.main(["prepare-clip", str(path), str(out1)])
+    sd = torch.load(out1, weights_only=False)
+    assert math.isnan(float(sd.pop("logit_scale")))
+    _same(sd, student.model.state_dict())
+    _same({k: v for k, v in load_clip_model(str(out1), precision="fp32").state_dict().items() if k != "logit_scale"},
+          student.model.state_dict())
+    C.main(["prepare", str(path), str(out2), "--prefix", "teacher.model"])
+    ck = torch.load(out2, weights_only=False)
+    assert ck["epoch"] == 7 and ck["optimizer_states"] == ["opaque"]
+    _same(ck["state_dict"], teacher.model.state_dict())

@@ -456,3 +456,22 @@ def test_other_clip_vit_geometries_match_oracle(tag):
         else:
             assert np.abs(got_v - ref_v).max() < 2e-2 and np.abs(got_t - ref_t).max() < 2e-2
             assert _signal_rel_err(got_t, ref_t) < 0.15
+
+
+def test_apply_wise_ft_files(tmp_path, tiny_state_dict):
+    """`python -m fitclip_amd.checkpoint apply-wise-ft A B OUT --weight-for-2 w` (scripts/apply_wise_ft.py): two
+    state-dict files in, the blended state dict out, bit-identical to the torch expression; a missing `logit_scale`
+    comes out as NaN."""
+    from fitclip_amd import checkpoint as C
+    d = synth.TINY
+    sd1 = {k: torch.from_numpy(v) for k, v in tiny_state_dict.items()}
+    sd2 = {k: torch.from_numpy(v) for k, v in synth.perturbed_state_dict(tiny_state_dict, d, seed=4, rel=0.1).items()}
+    p1, p2, out = tmp_path / "a.pt", tmp_path / "b.pt", tmp_path / "wise.pt"
+    torch.save(sd1, p1)
+    torch.save(sd2, p2)
+    C.main(["apply-wise-ft", str(p1), str(p2), str(out), "--weight-for-2", "0.3"])
+    got = torch.load(out, weights_only=False)
+    assert torch.isnan(got.pop("logit_scale")).all()  # NaN blended with NaN
+    assert set(got) == set(sd1)
+    for k in sd1:
+        assert torch.equal(got[k], (1 - 0.3) * sd1[k] + 0.3 * sd2[k]), k
