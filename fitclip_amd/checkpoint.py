@@ -5,7 +5,8 @@ Mirrors (behaviour, not code):
     prefix (a missing trailing dot is added), prefix stripped;
   * `scripts/checkpoint_to_state_dict.py` -> `python -m fitclip_amd.checkpoint INPUT [--prefix encoder.model.] > out.pt`;
   * `scripts/prepare_trained_clip_checkpoint_for_evaluation.py`, `scripts/prepare_trained_checkpoint_for_evaluation.py`,
-    `scripts/apply_wise_ft.py` -> the sub-commands `prepare-clip`, `prepare`, `apply-wise-ft` (file in, file out);
+    `scripts/open_clip_checkpoint_to_model.py`, `scripts/apply_wise_ft.py` -> the sub-commands `prepare-clip`, `prepare`,
+    `open-clip`, `apply-wise-ft` (file in, file out);
   * `aligner/text_video_retrieval.py:101-131` -> `load_module_state_dict`: a plain retrieval module silently drops the
     `teacher*` keys of a teacher-student checkpoint, and reports the other mismatches with torch's own wording;
   * the module-level keys a Lightning checkpoint of the reference holds: `encoder.<param>`, `logit_scale`, and for the
@@ -146,6 +147,15 @@ def prepare_trained_checkpoint(input_path: TYPE_PATH, output_path: TYPE_PATH, pr
     torch.save(checkpoint, os.fspath(output_path))
 
 
+def open_clip_checkpoint_to_model(input_path: TYPE_PATH, output_path: TYPE_PATH) -> None:
+    """open_clip training checkpoint -> bare state dict (`scripts/open_clip_checkpoint_to_model.py`): the wrapper prefix
+    (`model.` or `module.`, decided by the FIRST key) is cut from the front of every key."""
+    state_dict = _load(input_path)["state_dict"]
+    first_key = next(iter(state_dict))
+    prefix = next(p for p in ("model", "module") if first_key.startswith(p + "."))  # StopIteration if neither: as there
+    torch.save({k[len(prefix) + 1:]: v for k, v in state_dict.items()}, os.fspath(output_path))
+
+
 def apply_wise_ft(input_path1: TYPE_PATH, input_path2: TYPE_PATH, output_path: TYPE_PATH, weight_for_2: float = 0.5,
                   device: Union[str, torch.device] = "cuda") -> None:
     """WiSE-FT of two CLIP checkpoint FILES, written as a bare state dict (`scripts/apply_wise_ft.py`): both models are
@@ -162,7 +172,7 @@ def apply_wise_ft(input_path1: TYPE_PATH, input_path2: TYPE_PATH, output_path: T
 # ----------------------------------------------------------------------------------------------------------- CLI
 def main(argv: Union[List[str], None] = None) -> None:
     """`python -m fitclip_amd.checkpoint INPUT [--prefix P]`  (state dict to stdout, as checkpoint_to_state_dict.py), or
-    one of the sub-commands `prepare-clip`, `prepare`, `apply-wise-ft`."""
+    one of the sub-commands `prepare-clip`, `prepare`, `open-clip`, `apply-wise-ft`."""
     argv = list(sys.argv[1:] if argv is None else argv)
     tools = {"prepare-clip": prepare_trained_clip_checkpoint, "prepare": prepare_trained_checkpoint}
     if argv and argv[0] in tools:
@@ -172,6 +182,13 @@ def main(argv: Union[List[str], None] = None) -> None:
         parser.add_argument("--prefix", default="encoder.model.")
         args = parser.parse_args(argv[1:])
         tools[argv[0]](args.input_path, args.output_path, prefix=args.prefix)
+        return
+    if argv and argv[0] == "open-clip":
+        parser = argparse.ArgumentParser(prog="fitclip_amd.checkpoint open-clip")
+        parser.add_argument("input_path", metavar="INPUT_FILE")
+        parser.add_argument("output_path", metavar="OUTPUT_FILE")
+        args = parser.parse_args(argv[1:])
+        open_clip_checkpoint_to_model(args.input_path, args.output_path)
         return
     if argv and argv[0] == "apply-wise-ft":
         parser = argparse.ArgumentParser(prog="fitclip_amd.checkpoint apply-wise-ft",

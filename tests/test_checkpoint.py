@@ -151,3 +151,18 @@ def test_prepare_tools(tmp_path):
     ck = torch.load(out2, weights_only=False)
     assert ck["epoch"] == 7 and ck["optimizer_states"] == ["opaque"]
     _same(ck["state_dict"], teacher.model.state_dict())
+
+
+def test_open_clip_checkpoint_conversion(tmp_path):
+    """scripts/open_clip_checkpoint_to_model.py: the prefix of the first key (`module.` under DDP, `model.` otherwise)
+    is cut from every key."""
+    for prefix in ("module", "model"):
+        src, dst = tmp_path / f"{prefix}.pt", tmp_path / f"{prefix}_out.pt"
+        torch.save({"epoch": 3, "state_dict": {f"{prefix}.visual.proj": torch.ones(2), f"{prefix}.logit_scale": torch.tensor(4.6)}}, src)
+        C.main(["open-clip", str(src), str(dst)])
+        out = torch.load(dst, weights_only=False)
+        assert sorted(out) == ["logit_scale", "visual.proj"] and float(out["logit_scale"]) == pytest.approx(4.6)
+    bad = tmp_path / "bad.pt"
+    torch.save({"state_dict": {"encoder.x": torch.zeros(1)}}, bad)
+    with pytest.raises(StopIteration):
+        C.open_clip_checkpoint_to_model(bad, tmp_path / "never.pt")
