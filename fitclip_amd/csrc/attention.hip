@@ -512,6 +512,130 @@ __global__ void __launch_bounds__(NW * 64) attn_bf16_flash_kernel(const bf16* __
   }
 }
 
+// ---- exact-fp32 attention on the fp32-input matrix cores (`v_mfma_f32_16x16x4_f32`: fp32 products, fp32 accumulate),
+// for sequences of up to NKT * 16 tokens; same structure as attn_bf16_v2_kernel with fp32 operands:
+//   * K and V stay row-major [key][64 floats] (256-byte rows) in LDS, filled by LDS-DMA (a piece = 4 rows); the 16-byte
+//     chunk index of a row is XORed with (key & 15) on the source side.
+//   * S^T = K.Q^T: lane (r, g) reads K[key r][16 c + 4 g .. +3] with ONE ds_read_b128 per chunk c and feeds the four
+//     floats to four MFMAs (k index g <-> d = 16 c + 4 g + e); the Q fragments are read from global the same way, so the
+//     k permutation is the same on both operands.  Conflict-free under the XOR above.
+//   * P.V as O^T = V^T.P^T: the S^T accumulator register e of key tile t is the B operand of MFMA e (k index g <-> key
+//     16 t + 4 g + e); its A operand V[that key][16 n + r] is one ds_read_b32 (conflict-free as well).
+//   * softmax in registers with the accurate expf; each lane ends with 4 consecutive d of one query: float4 stores.
+// One 16-query tile per wave, NKT waves.
+template <int NKT, bool CAUSAL>
+__global__ void __launch_bounds__(NKT * 64) attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                int S, int heads) {
+  constexpr int NK = NKT * 16;
+  constexpr int OFF_V = NK * 256;
+  constexpr int NPIECE = (NK / 4 + NKT - 1) / NKT;  // 4-row pieces per wave, for K and again for V
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int D = heads * 64;
+  const long ld = 3L * D;
+  const float* base = qkv + (long)seq * S * ld + h * 64;
+  const int r = lane & 15, g = lane >> 4;
+  const int nqt = (S + 15) >> 4;
+  const int qt = wave;
+
+  {  // stage K, then V: lane l of a piece -> row l >> 4, chunk l & 15
+    const int prow = lane >> 4, pch = lane & 15;
+#pragma unroll
+    for (int isv = 0; isv < 2; ++isv) {
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) {
+        const int piece = wave + j * NKT;
+        if (piece < NK / 4) {
+          const int row = piece * 4 + prow;
+          const int srow = min(row, S - 1);  // padded keys read a valid row; they are masked / multiplied by P = 0
+          const float* src = base + (isv ? 2 * D : D) + (long)srow * ld + ((pch ^ (row & 15)) << 2);
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)(smem + (isv ? OFF_V : 0) + piece * 1024), 16, 0, 0);
+        }
+      }
+    }
+  }
+  // Q fragments: lane (r, g) holds Q[query r][16 c + 4 g .. +3], pre-scaled by 1/sqrt(64) (exact: a power of two)
+  f32x4 qf[4];
+  {
+    const float* qrow = base + (long)min(qt * 16 + r, S - 1) * ld + 4 * g;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c) * 0.125f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (qt >= nqt) return;
+
+  const int query = qt * 16 + r;
+  f32x4 sT[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (t * 16 < S && (!CAUSAL || t <= qt)) {
+      const char* krow = smem + (t * 16 + r) * 256;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + (((4 * c + g) ^ r) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[c][e], acc, 0, 0, 0);
+      }
+    }
+    sT[t] = acc;
+  }
+  float mx = kNegInf;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = t * 16 + 4 * g + e;
+      if (key >= S || (CAUSAL && key > query)) sT[t][e] = kNegInf;
+      mx = fmaxf(mx, sT[t][e]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = expf(sT[t][e] - mx);
+      sT[t][e] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (t * 16 >= S || (CAUSAL && t > qt)) continue;  // every P of the tile is zero
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = t * 16 + 4 * g + e;               // key & 15 = 4 g + e
+      const char* vrow = smem + OFF_V + key * 256 + (r & 3) * 4;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float vf = *reinterpret_cast<const float*>(vrow + (((4 * n + (r >> 2)) ^ (4 * g + e)) << 4));
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sT[t][e], o[n], 0, 0, 0);
+      }
+    }
+  }
+  // o[n][e] = O(query r, d = 16 n + 4 g + e)
+  if (query < S) {
+    float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[n] * inv;
+  }
+}
+
 // f32 parity kernel: thread per query (256 queries per workgroup), K/V rows broadcast from LDS in chunks of `kc` keys
 // (any sequence length; one chunk up to 256 keys), online softmax in key order.
 template <bool CAUSAL>
@@ -634,6 +758,17 @@ int launch_bf16_flash(const void* qkv, void* out, int n_seq, int S, int heads, h
   return launch_bf16_flash_nw<4>(qkv, out, n_seq, S, heads, st);
 }
 
+template <int NKT, bool CAUSAL>
+int launch_f32_mfma(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
+  constexpr int lds = 2 * NKT * 16 * 256;
+  if (lds > 64 * 1024 && raise_dynamic_lds((const void*)attn_f32_mfma_kernel<NKT, CAUSAL>, lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "attention(f32 mfma): cannot raise dynamic LDS");
+  hipLaunchKernelGGL((attn_f32_mfma_kernel<NKT, CAUSAL>), dim3(n_seq * heads), dim3(NKT * 64), lds, st,
+                     (const float*)qkv, (float*)out, S, heads);
+  FC_CHECK_LAUNCH("attention(f32 mfma)");
+  return FC_OK;
+}
+
 template <int NKT>
 int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
   constexpr int NK = NKT * 16;
@@ -667,6 +802,14 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
     if (S <= 96) return launch_bf16<6>(qkv, out, n_seq, S, heads, causal, stream);
     if (S <= 224) return launch_bf16<14>(qkv, out, n_seq, S, heads, causal, stream);
     return fail(FC_EINVAL, "attention(bf16): sequence length %d > 224 not supported", S);
+  }
+  static const bool f32_valu = getenv("FITCLIP_ATTN_F32_VALU") != nullptr;  // A/B switch for the thread-per-query kernel
+  if (!f32_valu && S <= 224) {
+    if (S <= 96)
+      return causal ? launch_f32_mfma<6, true>(qkv, out, n_seq, S, heads, stream)
+                    : launch_f32_mfma<6, false>(qkv, out, n_seq, S, heads, stream);
+    return causal ? launch_f32_mfma<14, true>(qkv, out, n_seq, S, heads, stream)
+                  : launch_f32_mfma<14, false>(qkv, out, n_seq, S, heads, stream);
   }
   const int kc = std::min(S, 256), lds = kc * 64 * 4 * 2;
   auto k0 = attn_f32_kernel<false>;
