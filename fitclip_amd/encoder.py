@@ -5,6 +5,7 @@ tokenizer / transform / frame-sampler factories and `should_pad_batch` have the 
 """
 from __future__ import annotations
 
+import os
 import zlib
 from typing import Iterable, Iterator, Mapping, Optional
 
@@ -19,6 +20,9 @@ from .plugin_api import (TYPE_TEXT_INPUT, TYPE_TOKENIZER, TYPE_TRANSFORM, TYPE_V
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)  # clip_video_text_encoder.py:72
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+_OVERLAP_TEXT = os.environ.get("FITCLIP_OVERLAP_TEXT", "1") not in ("0", "")  # A/B switch of the two-stream forward
 
 
 class HashTokenizer:
@@ -52,6 +56,7 @@ class ClipVideoTextEncoder(VideoTextEncoder):
         self.num_frames = num_frames
         self.bpe_path = bpe_path  # local bpe_simple_vocab_16e6.txt.gz; None -> HashTokenizer (framing only)
         self.mean, self.std = CLIP_MEAN, CLIP_STD
+        self._side_stream = None  # second HIP stream of the two-stream forward (created on first use)
         # Same as the reference (:75-77): the CLIP temperature is unused, drop the parameter so it is not in
         # `named_parameters()` (WiSE) nor in the optimiser.
         if hasattr(self.model, "logit_scale"):
@@ -77,6 +82,29 @@ class ClipVideoTextEncoder(VideoTextEncoder):
     def encode_text(self, text: TYPE_TEXT_INPUT) -> torch.Tensor:
         """{"input_ids": int [B, 77]} -> unit-norm f32 [B, E] - reference :92-94."""
         return ops.l2_normalize(self.model.encode_text(text["input_ids"]))
+
+    def forward(self, video: TYPE_VIDEO_INPUT, text: TYPE_TEXT_INPUT):  # noqa: signature of VideoTextEncoder.forward
+        """(encode_video(video), encode_text(text)) - reference video_text_encoder.py:21-22.
+
+        The text tower (2 % of the FLOPs, GEMMs of 150-600 tiles that leave CUs idle) is enqueued on a second HIP stream
+        BEFORE the visual tower is enqueued on the caller's stream, so its kernels fill the shadows of the visual
+        tower's memory-bound kernels (LayerNorm, attention): -1.4 % step time, identical results.  The caller's stream
+        waits for the side stream before returning, so the outputs behave like any other tensor of that stream.
+        FITCLIP_OVERLAP_TEXT=0 restores the sequential order."""
+        if not _OVERLAP_TEXT or not video.is_cuda:
+            return self.encode_video(video), self.encode_text(text)
+        self.model._ensure_ready()  # weight packing (first call / after a weight update) happens on the caller's stream
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=video.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            encoded_text = self.encode_text(text)
+        encoded_video = self.encode_video(video)
+        main.wait_stream(side)
+        encoded_text.record_stream(main)
+        return encoded_video, encoded_text
 
     def get_tokenizer(self) -> TYPE_TOKENIZER:
         if self.bpe_path:
