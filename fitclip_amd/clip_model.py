@@ -23,6 +23,10 @@ from .synth import ClipDims, VIT_B_16, parameter_shapes
 
 _PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
                "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
+# Opt-in: slices of a big image batch go to this many HIP streams (`CLIP._encode_image_lanes`).  4 gives ~1 % more
+# throughput at 2048 frames, but kernels of different slices then overlap in time, so per-kernel durations (the roofline
+# evidence of bench.py and rocprofv3) stop describing a kernel that owns the chip: off (1) by default.
+_IMAGE_STREAMS = max(1, int(os.environ.get("FITCLIP_IMAGE_STREAMS", "1")))
 _IGNORED_KEYS = ("logit_scale", "input_resolution", "context_length", "vocab_size")  # JIT-archive leftovers
 
 
@@ -141,11 +145,11 @@ class CLIP(nn.Module):
             rt.fingerprint = fp
         return rt
 
-    def _workspace(self, rt: "_Runtime", tower: int, n: int) -> torch.Tensor:
+    def _workspace(self, rt: "_Runtime", tower: int, n: int, lane: int = 0) -> torch.Tensor:
         need = _lib.load().fc_workspace_bytes(rt.handle, tower, n)
-        ws = rt.workspace.get(tower)
+        ws = rt.workspace.get((tower, lane))
         if ws is None or ws.numel() < need:
-            rt.workspace[tower] = ws = torch.empty(need, dtype=torch.uint8, device=self._device())
+            rt.workspace[(tower, lane)] = ws = torch.empty(need, dtype=torch.uint8, device=self._device())
         return ws
 
     # --------------------------------------------------------------------------------------------------- encoders
@@ -161,10 +165,51 @@ class CLIP(nn.Module):
         out = torch.empty((n, d.embed_dim), dtype=torch.float32, device=image.device)
         if n:
             with torch.cuda.device(image.device):
-                ws = self._workspace(rt, 0, n)
-                _lib.check(_lib.load().fc_encode_image(rt.handle, image.data_ptr(), n, out.data_ptr(), ws.data_ptr(),
-                                                       ws.numel(), _lib.current_stream()), "fc_encode_image")
+                lanes = _IMAGE_STREAMS if n >= _IMAGE_STREAMS * self._chunk_frames() else 1
+                if lanes == 1:
+                    ws = self._workspace(rt, 0, n)
+                    _lib.check(_lib.load().fc_encode_image(rt.handle, image.data_ptr(), n, out.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), _lib.current_stream()),
+                               "fc_encode_image")
+                else:
+                    self._encode_image_lanes(rt, image, out, lanes)
         return out
+
+    def _chunk_frames(self) -> int:
+        return self.chunk_frames if self.chunk_frames > 0 else 512  # the library's default chunk
+
+    def _encode_image_lanes(self, rt: "_Runtime", image: torch.Tensor, out: torch.Tensor, lanes: int) -> None:
+        """Large batches (>= `lanes` chunks): contiguous slices of the frames go to `lanes` HIP streams (the caller's +
+        side streams), each with its own workspace, so that kernels of different slices interleave: the tail of one
+        slice's persistent GEMM overlaps the head of another slice's next kernel.  Measured with 2048 frames: 4 lanes
+        -1 % step time, 2 lanes +0.4 % (two persistent GEMMs then mostly fight for the same CUs).  Rows are independent,
+        so the result is bit-identical; the caller's stream waits for the side streams before returning."""
+        n, res = image.shape[0], 3 * image.shape[2] * image.shape[3]
+        chunk = self._chunk_frames()
+        per = -(-(-(-n // lanes)) // chunk) * chunk  # ceil(n / lanes) rounded up to whole chunks
+        main = torch.cuda.current_stream()
+        if not hasattr(rt, "side_streams"):
+            rt.side_streams = []
+        while len(rt.side_streams) < lanes - 1:
+            rt.side_streams.append(torch.cuda.Stream(device=image.device))
+        lib = _lib.load()
+        start = 0
+        used = []
+        for lane in range(lanes):
+            cnt = min(per, n - start)
+            if cnt <= 0:
+                break
+            stream = main if lane == 0 else rt.side_streams[lane - 1]
+            if lane:
+                stream.wait_stream(main)
+                used.append(stream)
+            ws = self._workspace(rt, 0, cnt, lane)
+            _lib.check(lib.fc_encode_image(rt.handle, image.data_ptr() + start * res * 4, cnt,
+                                           out.data_ptr() + start * out.shape[1] * 4, ws.data_ptr(), ws.numel(),
+                                           stream.cuda_stream), "fc_encode_image")
+            start += cnt
+        for stream in used:
+            main.wait_stream(stream)
 
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:

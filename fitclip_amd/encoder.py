@@ -56,6 +56,7 @@ class ClipVideoTextEncoder(VideoTextEncoder):
         self.num_frames = num_frames
         self.bpe_path = bpe_path  # local bpe_simple_vocab_16e6.txt.gz; None -> HashTokenizer (framing only)
         self.mean, self.std = CLIP_MEAN, CLIP_STD
+        self.overlap_text = _OVERLAP_TEXT  # two-stream forward (see `forward`); plain attribute, can be switched off
         self._side_stream = None  # second HIP stream of the two-stream forward (created on first use)
         # Same as the reference (:75-77): the CLIP temperature is unused, drop the parameter so it is not in
         # `named_parameters()` (WiSE) nor in the optimiser.
@@ -91,7 +92,7 @@ class ClipVideoTextEncoder(VideoTextEncoder):
         tower's memory-bound kernels (LayerNorm, attention): -1.4 % step time, identical results.  The caller's stream
         waits for the side stream before returning, so the outputs behave like any other tensor of that stream.
         FITCLIP_OVERLAP_TEXT=0 restores the sequential order."""
-        if not _OVERLAP_TEXT or not video.is_cuda:
+        if not self.overlap_text or not video.is_cuda:
             return self.encode_video(video), self.encode_text(text)
         self.model._ensure_ready()  # weight packing (first call / after a weight update) happens on the caller's stream
         main = torch.cuda.current_stream()
