@@ -475,3 +475,23 @@ def test_apply_wise_ft_files(tmp_path, tiny_state_dict):
     assert set(got) == set(sd1)
     for k in sd1:
         assert torch.equal(got[k], (1 - 0.3) * sd1[k] + 0.3 * sd2[k]), k
+
+
+def test_two_stream_forward_and_image_lanes_are_bit_identical(vitb16_state_dict, monkeypatch):
+    """`forward` with the text tower on a side stream, and `encode_image` with slices of a big batch on several streams
+    (`FITCLIP_IMAGE_STREAMS`), return exactly what the single-stream path returns (rows are independent; the caller's
+    stream waits for the side streams)."""
+    from fitclip_amd import clip_model
+    d = synth.VIT_B_16
+    enc = _encoder(vitb16_state_dict, "bf16", chunk_frames=32)
+    enc.num_frames = 2
+    video = torch.from_numpy(synth.make_video(70, 2, d, seed=41)).to(DEV)   # 140 frames: 4 lanes of 64 / 64 / 12 / -
+    text = {"input_ids": torch.from_numpy(synth.make_text(33, d, seed=41)).to(DEV)}
+    enc.overlap_text = False
+    ref_v, ref_t = enc(video=video, text=text)
+    enc.overlap_text = True
+    for lanes in (1, 2, 4):
+        monkeypatch.setattr(clip_model, "_IMAGE_STREAMS", lanes)
+        got_v, got_t = enc(video=video, text=text)
+        torch.cuda.synchronize()
+        assert torch.equal(got_v, ref_v) and torch.equal(got_t, ref_t), lanes
