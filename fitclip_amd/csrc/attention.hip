@@ -523,12 +523,12 @@ __global__ void __launch_bounds__(NW * 64) attn_bf16_flash_kernel(const bf16* __
 //     16 t + 4 g + e); its A operand V[that key][16 n + r] is one ds_read_b32 (conflict-free as well).
 //   * softmax in registers with the accurate expf; each lane ends with 4 consecutive d of one query: float4 stores.
 // One 16-query tile per wave, NKT waves.
-template <int NKT, bool CAUSAL>
-__global__ void __launch_bounds__(NKT * 64) attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <int NKT, int NW, bool CAUSAL>
+__global__ void __launch_bounds__(NW * 64) attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                 int S, int heads) {
   constexpr int NK = NKT * 16;
   constexpr int OFF_V = NK * 256;
-  constexpr int NPIECE = (NK / 4 + NKT - 1) / NKT;  // 4-row pieces per wave, for K and again for V
+  constexpr int NPIECE = (NK / 4 + NW - 1) / NW;  // 4-row pieces per wave, for K and again for V
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -538,15 +538,13 @@ __global__ void __launch_bounds__(NKT * 64) attn_f32_mfma_kernel(const float* __
   const float* base = qkv + (long)seq * S * ld + h * 64;
   const int r = lane & 15, g = lane >> 4;
   const int nqt = (S + 15) >> 4;
-  const int qt = wave;
-
   {  // stage K, then V: lane l of a piece -> row l >> 4, chunk l & 15
     const int prow = lane >> 4, pch = lane & 15;
 #pragma unroll
     for (int isv = 0; isv < 2; ++isv) {
 #pragma unroll
       for (int j = 0; j < NPIECE; ++j) {
-        const int piece = wave + j * NKT;
+        const int piece = wave + j * NW;
         if (piece < NK / 4) {
           const int row = piece * 4 + prow;
           const int srow = min(row, S - 1);  // padded keys read a valid row; they are masked / multiplied by P = 0
@@ -558,6 +556,13 @@ __global__ void __launch_bounds__(NKT * 64) attn_f32_mfma_kernel(const float* __
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  constexpr int QPW = (NKT + NW - 1) / NW;  // 16-query tiles per wave (1 when NW == NKT)
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+  const int qt = wave + qi * NW;
+  if (qt >= nqt) break;
   // Q fragments: lane (r, g) holds Q[query r][16 c + 4 g .. +3], pre-scaled by 1/sqrt(64) (exact: a power of two)
   f32x4 qf[4];
   {
@@ -565,10 +570,6 @@ __global__ void __launch_bounds__(NKT * 64) attn_f32_mfma_kernel(const float* __
 #pragma unroll
     for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c) * 0.125f;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (qt >= nqt) return;
-
   const int query = qt * 16 + r;
   f32x4 sT[NKT];
 #pragma unroll
@@ -634,6 +635,7 @@ __global__ void __launch_bounds__(NKT * 64) attn_f32_mfma_kernel(const float* __
 #pragma unroll
     for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[n] * inv;
   }
+  }  // q-tile loop
 }
 
 // f32 parity kernel: thread per query (256 queries per workgroup), K/V rows broadcast from LDS in chunks of `kc` keys
@@ -758,12 +760,12 @@ int launch_bf16_flash(const void* qkv, void* out, int n_seq, int S, int heads, h
   return launch_bf16_flash_nw<4>(qkv, out, n_seq, S, heads, st);
 }
 
-template <int NKT, bool CAUSAL>
+template <int NKT, int NW, bool CAUSAL>
 int launch_f32_mfma(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
   constexpr int lds = 2 * NKT * 16 * 256;
-  if (lds > 64 * 1024 && raise_dynamic_lds((const void*)attn_f32_mfma_kernel<NKT, CAUSAL>, lds) != hipSuccess)
+  if (lds > 64 * 1024 && raise_dynamic_lds((const void*)attn_f32_mfma_kernel<NKT, NW, CAUSAL>, lds) != hipSuccess)
     return fail(FC_ELAUNCH, "attention(f32 mfma): cannot raise dynamic LDS");
-  hipLaunchKernelGGL((attn_f32_mfma_kernel<NKT, CAUSAL>), dim3(n_seq * heads), dim3(NKT * 64), lds, st,
+  hipLaunchKernelGGL((attn_f32_mfma_kernel<NKT, NW, CAUSAL>), dim3(n_seq * heads), dim3(NW * 64), lds, st,
                      (const float*)qkv, (float*)out, S, heads);
   FC_CHECK_LAUNCH("attention(f32 mfma)");
   return FC_OK;
@@ -804,12 +806,15 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
     return fail(FC_EINVAL, "attention(bf16): sequence length %d > 224 not supported", S);
   }
   static const bool f32_valu = getenv("FITCLIP_ATTN_F32_VALU") != nullptr;  // A/B switch for the thread-per-query kernel
-  if (!f32_valu && S <= 224) {
+  if (!f32_valu && S <= 288) {  // K and V of one (sequence, head) fit LDS in fp32 up to 288 tokens (144 KiB)
     if (S <= 96)
-      return causal ? launch_f32_mfma<6, true>(qkv, out, n_seq, S, heads, stream)
-                    : launch_f32_mfma<6, false>(qkv, out, n_seq, S, heads, stream);
-    return causal ? launch_f32_mfma<14, true>(qkv, out, n_seq, S, heads, stream)
-                  : launch_f32_mfma<14, false>(qkv, out, n_seq, S, heads, stream);
+      return causal ? launch_f32_mfma<6, 6, true>(qkv, out, n_seq, S, heads, stream)
+                    : launch_f32_mfma<6, 6, false>(qkv, out, n_seq, S, heads, stream);
+    if (S <= 224)
+      return causal ? launch_f32_mfma<14, 14, true>(qkv, out, n_seq, S, heads, stream)
+                    : launch_f32_mfma<14, 14, false>(qkv, out, n_seq, S, heads, stream);
+    return causal ? launch_f32_mfma<18, 8, true>(qkv, out, n_seq, S, heads, stream)
+                  : launch_f32_mfma<18, 8, false>(qkv, out, n_seq, S, heads, stream);
   }
   const int kc = std::min(S, 256), lds = kc * 64 * 4 * 2;
   auto k0 = attn_f32_kernel<false>;
