@@ -6,15 +6,21 @@ Lightning: `key=value` overrides, `_target_` instantiation of the encoder config
 {"video", "text": {"input_ids"}, "video_id"}, `TextVideoRetrievalModule(init_temperature=0.015)`
 (config/trainer.yaml:17-20), metric names `loss/val`, `r1`, `r5`, `r10`, `mr`.  One JSON line on stdout.
 
-Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N -m fitclip_amd ...`; every rank evaluates its
-own contiguous shard of the clips (exact, no padding) and the embeddings are all-gathered once before scoring.
+Multi-GPU: `gpus=N` starts N rank processes (one per GPU, RCCL) itself, or launch with
+`python -m torch.distributed.run --nproc-per-node N -m fitclip_amd ...`; every rank evaluates its own contiguous shard
+of the clips (exact, no padding) and the embeddings are all-gathered once before scoring.  `backend=gloo` rehearses the
+multi-rank path on a single GPU (all ranks on device 0, collectives staged through the host).
 """
 from __future__ import annotations
 
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises HIP (RCCL needs dmabuf IPC here)
 from pathlib import Path
 from typing import Any, Dict, Mapping
 
@@ -28,6 +34,7 @@ CONFIG_DIR = Path(__file__).resolve().parent / "config"
 DEFAULTS: Dict[str, Any] = {
     "command": "evaluate", "encoder": "clip_vit_b_16", "data": "synthetic", "seed": 42, "n_clips": 64,
     "num_frames": 4, "eval_batch_size": 32, "init_temperature": 0.015, "precision": None, "weight_for_2": None,
+    "gpus": 1, "backend": "nccl",
 }
 
 
@@ -81,7 +88,7 @@ def load_encoder_config(name: str, cfg: Mapping[str, Any], device: Any = None) -
 def evaluate(cfg: Mapping[str, Any]) -> Dict[str, float]:
     from .retrieval import TextVideoRetrievalModule
     rank, world = D.world()
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    device = _device(cfg)
     torch.cuda.set_device(device)
     torch.manual_seed(cfg["seed"])
     encoder = instantiate(load_encoder_config(cfg["encoder"], cfg, device)).to(device)
@@ -102,14 +109,41 @@ def evaluate(cfg: Mapping[str, Any]) -> Dict[str, float]:
         return module.validation_epoch_end()
 
 
+def _device(cfg: Mapping[str, Any]) -> torch.device:
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if cfg.get("backend") == "gloo":  # rehearsal: every rank on the one GPU that is there
+        local_rank %= max(1, torch.cuda.device_count())
+    return torch.device("cuda", local_rank)
+
+
+def _self_launch(argv) -> int:
+    """gpus=N without a torch.distributed.run environment: N fresh rank processes, started before this process has
+    touched the GPU (a process that has initialised HIP is never re-exec'ed)."""
+    n = parse_overrides(argv)["gpus"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "fitclip_amd", *argv]
+    return subprocess.run(cmd, env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}).returncode
+
+
 def main(argv=None) -> None:
-    cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
+    argv = sys.argv[1:] if argv is None else list(argv)
+    cfg = parse_overrides(argv)
     if cfg["command"] not in ("evaluate", "validate"):
         raise SystemExit("only command=evaluate (alias validate) is implemented: the inference path of the reference")
+    if cfg["gpus"] > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        device = _device(cfg)
+        torch.cuda.set_device(device)  # before the process group: RCCL binds the communicator to the current device
+        if cfg["backend"] == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(cfg["backend"])
     metrics = evaluate(cfg)
     if D.world()[0] == 0:
         print(json.dumps({"command": cfg["command"], "encoder": cfg["encoder"], "n_clips": cfg["n_clips"],

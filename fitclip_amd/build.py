@@ -18,6 +18,18 @@ HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", REPO / "include" / "fitcli
 ARCH = "gfx950"
 
 
+def source_fingerprint() -> str:
+    """Hash of every kernel / ABI source the library is built from.  Profiling artefacts (profiles/traffic_*.json) are
+    stamped with it, and bench.py refuses a PMC pass that was made with other sources than the ones in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([*(CSRC / s for s in SOURCES), *CSRC.glob("*.h"), *CSRC.glob("*.inc"),
+                        *(REPO / "include").glob("*.h")]):
+        h.update(path.name.encode())
+        h.update(path.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

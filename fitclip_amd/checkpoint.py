@@ -32,14 +32,32 @@ import torch
 TYPE_PATH = Union[str, "os.PathLike[str]"]
 
 
-def _load(path: TYPE_PATH) -> Any:
+def _torch_load(file: Any, trusted: bool) -> Any:
+    """`weights_only=True` first: bare state dicts and most Lightning checkpoints are tensors + plain containers and
+    never need the unpickler.  Only a file the CALLER declares trusted (`trusted=True` / FITCLIP_TRUST_CHECKPOINTS=1) is
+    retried with the full unpickler, which can execute code embedded in the file (Lightning checkpoints that pickle
+    hyper-parameter objects need it - the reference's `torch.load` did this unconditionally)."""
+    import pickle
+    try:
+        return torch.load(file, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not (trusted or os.environ.get("FITCLIP_TRUST_CHECKPOINTS") == "1"):
+            raise pickle.UnpicklingError(
+                f"{e}\nThis checkpoint holds pickled objects besides tensors.  If you trust its origin, load it with "
+                "trusted=True or set FITCLIP_TRUST_CHECKPOINTS=1.") from None
+        if hasattr(file, "seek"):
+            file.seek(0)
+        return torch.load(file, map_location="cpu", weights_only=False)
+
+
+def _load(path: TYPE_PATH, trusted: bool = False) -> Any:
     path = os.fspath(path)
     if "://" in path:
         raise FileNotFoundError(f"{path!r}: remote checkpoints cannot be fetched here (no network); pass a local file")
     if os.path.exists(path) and not os.path.isdir(path) and not os.path.isfile(path):  # a pipe
         with open(path, "rb") as f:
-            return torch.load(io.BytesIO(f.read()), map_location="cpu", weights_only=False)
-    return torch.load(path, map_location="cpu", weights_only=False)
+            return _torch_load(io.BytesIO(f.read()), trusted)
+    return _torch_load(path, trusted)
 
 
 def load_state_dict_file(path: TYPE_PATH) -> MutableMapping[str, torch.Tensor]:

@@ -101,7 +101,21 @@ class CLIP(nn.Module):
         if "logit_scale" not in sd and hasattr(self, "logit_scale"):
             # the reference re-creates a NaN logit_scale for checkpoints that lack it (clip_video_text_encoder.py:43-53)
             sd["logit_scale"] = torch.tensor(float("nan"))
+        self.invalidate_weights()
         return super().load_state_dict(sd, strict=strict)
+
+    def invalidate_weights(self) -> None:
+        """Tells the native side that parameter VALUES changed, so the kernel-layout copies (bf16 arena, transposed
+        projections) are rebuilt before the next encode.  Called by `load_state_dict`, `_apply` (`.to()`, `.float()`,
+        ...) and the trainer's optimiser step.  Writers that go through `param.data` (EMA updates, in-place init: such
+        writes do not bump `param._version`) must call it themselves."""
+        rt = self.__dict__.get("_rt")
+        if rt is not None:
+            rt.fingerprint = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_weights()
+        return super()._apply(fn, *args, **kwargs)
 
     # ----------------------------------------------------------------------------------------------------- native
     def _device(self) -> torch.device:
@@ -128,8 +142,13 @@ class CLIP(nn.Module):
             _lib.check(lib.fc_create(cfg, h), "fc_create")
             rt.handle, rt.key = h, key
         weights = self._named_weights()
-        fp = tuple((p.data_ptr(), p._version) for _, p in weights)
-        if fp != rt.fingerprint:
+        # (pointer, version counter) per parameter: catches re-allocation and ordinary in-place autograd-visible writes;
+        # `.data` writes are announced with `invalidate_weights()`.  Inference tensors have no version counter: a model
+        # built under torch.inference_mode() is simply repacked on every call.
+        fp = None
+        if not any(p.is_inference() for _, p in weights):
+            fp = tuple((p.data_ptr(), p._version) for _, p in weights)
+        if fp is None or fp != rt.fingerprint:
             with torch.cuda.device(dev):
                 for name, p in weights:
                     if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:

@@ -59,6 +59,18 @@ def all_gather_rows(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
     return torch.cat([gathered[r * biggest: r * biggest + c] for r, c in enumerate(counts)])
 
 
+def all_gather_many(tensors: Sequence[torch.Tensor], counts: Sequence[int]) -> List[torch.Tensor]:
+    """`all_gather_rows` of several [n_local, d_i] tensors in ONE collective (they are packed side by side into one
+    [n_local, sum d_i] buffer): the (student video, student text, teacher video, teacher text) tuple the reference's
+    wrapper walks tensor by tensor (tensor_utils.py:48-66, teacher_student.py:143)."""
+    rank, world_size = world()
+    if world_size == 1:
+        return list(tensors)
+    widths = [t.shape[1] for t in tensors]
+    gathered = all_gather_rows(torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1), counts)
+    return [g.contiguous() for g in gathered.split(widths, dim=1)]
+
+
 def metrics_from_ranks(ranks: np.ndarray) -> Dict[str, float]:
     """R@1/5/10 = fraction of ranks < k (torchmetrics Recall(top_k), text_video_retrieval.py:21); MedianRank =
     lower-middle median + 1 (torch.median semantics, aligner/metrics.py:33-36)."""

@@ -144,6 +144,8 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
 def similarity(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     """alpha * a @ b^T in exact fp32 (text_video_retrieval.py:50,74)."""
     _dev(a, "a", torch.float32), _dev(b, "b", torch.float32)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError(f"similarity needs [na, d] and [nb, d], got {tuple(a.shape)} and {tuple(b.shape)}")
     na, nb = a.shape[0], b.shape[0]
     ld = (nb + 3) // 4 * 4
     buf = torch.empty((na, ld), dtype=torch.float32, device=a.device)

@@ -112,8 +112,8 @@ class TeacherStudentModule(VideoTextModule):
         rank, world_size = D.world()
         if world_size > 1:
             counts = [len(video)] * world_size  # training batches are equal-sized per rank (DDP)
-            video, text, teacher_video, teacher_text = (D.all_gather_rows(t, counts) for t in
-                                                        (video, text, teacher_video, teacher_text))
+            video, text, teacher_video, teacher_text = D.all_gather_many(
+                (video, text, teacher_video, teacher_text), counts)  # one collective for the four embeddings
         scores = self.step_scores(video, text)
         if labeled:
             return ops.nce_loss(scores)

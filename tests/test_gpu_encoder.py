@@ -23,6 +23,7 @@ from oracle import clip_oracle as O  # noqa: E402
 
 DEV = "cuda"
 F32_TOL = 2e-5
+BF16_TOL = 6e-3  # unit-norm embeddings, typical element 0.044; observed bf16 error 7e-4 .. 2.4e-3
 
 
 def _encoder(sd, precision, **kw):
@@ -83,7 +84,7 @@ def test_evaluate_goldens(golden_dir, tag, dims, request):
         else:
             assert _signal_rel_err(ev, g["encoded_videos"]) < 0.15
             assert _signal_rel_err(et, g["encoded_texts"]) < 0.15
-            assert np.abs(ev - g["encoded_videos"]).max() < 2e-2 and np.abs(et - g["encoded_texts"]).max() < 2e-2
+            assert np.abs(ev - g["encoded_videos"]).max() < BF16_TOL and np.abs(et - g["encoded_texts"]).max() < BF16_TOL
 
 
 def test_wise_encoder_matches_oracle(golden_dir, tiny_state_dict):
@@ -105,7 +106,7 @@ def test_wise_encoder_matches_oracle(golden_dir, tiny_state_dict):
         wise(enc, enc.model)  # different classes, as aligner/wise.py:20
 
 
-def test_recall_parity_on_planted_projection(tiny_state_dict):
+def test_recall_parity_on_an_ill_conditioned_task_fp32_exact_bf16_outside_north_star(tiny_state_dict):
     """A non-vacuous Recall@k check through both encoders.  Random towers give chance-level retrieval, so
     `text_projection` is FITTED (ridge regression on ORACLE features; 256 captions against a 128-wide tower, so the fit
     cannot interpolate) until captions retrieve their own clips ~89 % of the time; R@1/5/10/MedR of the fp32 and bf16
@@ -255,14 +256,15 @@ def test_evaluate_driver_reproduces_config1_golden(golden_dir, capsys):
     assert abs(out["loss/val"] - float(g["loss_val"])) < 2e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("clips,frames,n_text", [(256, 8, 256), (1024, 16, 1024)])
-def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_text):
+def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_text, precision):
     """BASELINE configs[1] (256 clips x 8 frames + 256 texts) and one rank's shard of configs[3] (1024 clips x 16
     frames + 1024 texts) at FULL size, checked through the size-independent property that a row's embedding does not
     depend on the rest of the batch: the big batch is built from 4 base clips / 8 base captions whose embeddings are
     computed alone (and those small cases are pinned to the oracle by the golden tests above)."""
     d = synth.VIT_B_16
-    enc = _encoder(vitb16_state_dict, "bf16")
+    enc = _encoder(vitb16_state_dict, precision)
     base_v = torch.from_numpy(synth.make_video(4, frames, d, seed=21)).to(DEV)
     base_t = torch.from_numpy(synth.make_text(8, d, seed=21)).to(DEV)
     ref_v = enc.encode_video(base_v)
@@ -284,7 +286,8 @@ def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_tex
     assert ranks.cpu().tolist() == want.tolist()
 
 
-def test_teacher_student_full_size_by_invariance(vitb16_state_dict):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_teacher_student_full_size_by_invariance(vitb16_state_dict, precision):
     """BASELINE configs[4] at full size: teacher + student ViT-B/16 forward over 512 clips x 8 frames and the KD / NCE
     similarity losses on the 512 x 512 score matrices.  The oracle cannot run this size, so: (i) the batch is built
     from 4 base clips / 8 base captions whose embeddings are computed alone (batch invariance, bit-exact); (ii) the
@@ -293,7 +296,7 @@ def test_teacher_student_full_size_by_invariance(vitb16_state_dict):
     d = synth.VIT_B_16
     n, f = 512, 8
     student_sd = synth.perturbed_state_dict(vitb16_state_dict, d, seed=5, rel=0.05)
-    student, teacher = _encoder(student_sd, "bf16"), _encoder(vitb16_state_dict, "bf16")
+    student, teacher = _encoder(student_sd, precision), _encoder(vitb16_state_dict, precision)
     student.num_frames = teacher.num_frames = f
     base_v = torch.from_numpy(synth.make_video(4, f, d, seed=31)).to(DEV)
     base_t = torch.from_numpy(synth.make_text(8, d, seed=31)).to(DEV)
@@ -454,7 +457,7 @@ def test_other_clip_vit_geometries_match_oracle(tag):
         if precision == "fp32":
             assert np.abs(got_v - ref_v).max() < F32_TOL and np.abs(got_t - ref_t).max() < F32_TOL
         else:
-            assert np.abs(got_v - ref_v).max() < 2e-2 and np.abs(got_t - ref_t).max() < 2e-2
+            assert np.abs(got_v - ref_v).max() < BF16_TOL and np.abs(got_t - ref_t).max() < BF16_TOL
             assert _signal_rel_err(got_t, ref_t) < 0.15
 
 
@@ -495,3 +498,108 @@ def test_two_stream_forward_and_image_lanes_are_bit_identical(vitb16_state_dict,
         got_v, got_t = enc(video=video, text=text)
         torch.cuda.synchronize()
         assert torch.equal(got_v, ref_v) and torch.equal(got_t, ref_t), lanes
+
+
+def test_wise_evaluate_at_webvid_val_shape_by_invariance(vitb16_state_dict):
+    """BASELINE configs[2]: `encoder=wise` (0.5 CLIP + 0.5 student, ViT-B/16) through the evaluate loop at the
+    WebVid-val shape the survey fixes (N = 4096 clips x 4 frames, one caption per clip, eval batches of 32), in the
+    reference's precision.  The oracle cannot run this size, so the 4096 clips / captions are drawn from 8 base clips /
+    16 base captions: (i) every embedding must equal, bit for bit, the embedding of its base item computed alone by the
+    same blended encoder (batch invariance); (ii) the blended parameters are bit-identical to `aligner.wise`'s
+    expression; (iii) R@1/5/10 / MedR of the epoch end equal the oracle's metric code applied to the device scores
+    (ties between duplicates are broken by index on both sides)."""
+    d = synth.VIT_B_16
+    n, f = 4096, 4
+    sd2 = synth.perturbed_state_dict(vitb16_state_dict, d, seed=9, rel=0.05)
+    enc = wise(_encoder(vitb16_state_dict, "fp32"), _encoder(sd2, "fp32"), weight_for_2=0.5)
+    enc.num_frames = f
+    name = "visual.transformer.resblocks.7.mlp.c_fc.weight"
+    want = (1 - 0.5) * torch.from_numpy(vitb16_state_dict[name]) + 0.5 * torch.from_numpy(sd2[name])
+    assert torch.equal(dict(enc.model.named_parameters())[name].cpu(), want)
+    base_v = torch.from_numpy(synth.make_video(8, f, d, seed=51)).to(DEV)
+    base_t = torch.from_numpy(synth.make_text(16, d, seed=51)).to(DEV)
+    ref_v, ref_t = enc.encode_video(base_v), enc.encode_text({"input_ids": base_t})
+    gen = torch.Generator().manual_seed(3)
+    pick_v, pick_t = torch.randint(0, 8, (n,), generator=gen).to(DEV), torch.randint(0, 16, (n,), generator=gen).to(DEV)
+    module = TextVideoRetrievalModule(enc, init_temperature=0.015)
+    for s in range(0, n, 32):
+        out = module.validation_step({"video": base_v[pick_v[s:s + 32]], "text": {"input_ids": base_t[pick_t[s:s + 32]]},
+                                      "video_id": list(range(s, s + 32))})
+        module.validation_step_end(out)
+    ev = torch.cat([o[0] for o in module._outputs])
+    et = torch.cat([o[1] for o in module._outputs])
+    assert torch.equal(ev, ref_v[pick_v]) and torch.equal(et, ref_t[pick_t])
+    got = module.validation_epoch_end()
+    scores = ops.similarity(et, ev).cpu()
+    ref = O.retrieval_metrics(scores)
+    for k in ("r1", "r5", "r10", "mr"):
+        assert got[k] == pytest.approx(ref[k]), (k, got, ref)
+    assert np.isfinite(got["loss/val"])
+
+
+def test_data_writes_are_picked_up_after_invalidate_weights(tiny_state_dict):
+    """`param.data` writes do not bump the autograd version counter, so the kernel-layout weight copies (bf16 arena,
+    transposed projections) would go stale: `CLIP.invalidate_weights()` (also called by load_state_dict / .to()) makes
+    the next encode repack.  Both precisions: fp32 uses the caller's tensors directly except for the projections."""
+    d = synth.TINY
+    video = torch.from_numpy(synth.make_video(3, 2, d, seed=2)).to(DEV)
+    ids = torch.from_numpy(synth.make_text(3, d, seed=2)).to(DEV)
+    for precision in ("fp32", "bf16"):
+        enc = _encoder(tiny_state_dict, precision)
+        v0, t0 = enc.encode_video(video), enc.encode_text({"input_ids": ids})
+        with torch.no_grad():
+            enc.model.visual.proj.data.mul_(-1.0)
+            enc.model.text_projection.data.mul_(-1.0)
+            enc.model.visual.transformer.resblocks[0].mlp.c_fc.weight.data.mul_(0.5)
+        enc.model.invalidate_weights()
+        v1, t1 = enc.encode_video(video), enc.encode_text({"input_ids": ids})
+        assert torch.allclose(t1, -t0, atol=1e-6), precision          # the transposed projection copy was rebuilt
+        assert (v1 + v0).abs().max() > 1e-3, precision                # and the block weight copy as well
+        sd = {k: v.detach().cpu().numpy() for k, v in enc.model.state_dict().items()}
+        fresh = _encoder(sd, precision)
+        assert torch.equal(fresh.encode_video(video), v1) and torch.equal(fresh.encode_text({"input_ids": ids}), t1)
+        enc.model.load_state_dict({k: torch.from_numpy(v) for k, v in tiny_state_dict.items()})  # invalidates by itself
+        assert torch.equal(enc.encode_video(video), v0)
+
+
+def test_similarity_rejects_mismatched_inner_dimensions():
+    a, b = torch.zeros(4, 64, device=DEV), torch.zeros(4, 128, device=DEV)
+    with pytest.raises(ValueError):
+        ops.similarity(a, b)
+    with pytest.raises(ValueError):
+        ops.similarity(a, b[0])
+
+
+def _run(cmd, timeout=900):
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, *cmd], capture_output=True, text=True, timeout=timeout, env=env,
+                         cwd=str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+    assert res.returncode == 0, res.stderr[-3000:]
+    import json
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_two_rank_evaluate_equals_single_rank():
+    """Rehearsal of the sharded path on ONE GPU: `python -m fitclip_amd command=evaluate gpus=2 backend=gloo` starts two
+    fresh rank processes (both on device 0; collectives staged through the host), each encodes its own contiguous shard,
+    embeddings are all-gathered once, ranks gathered - and the metrics equal the single-process run exactly."""
+    common = ["-m", "fitclip_amd", "command=evaluate", "encoder=clip_vit_b_16", "n_clips=22", "num_frames=1",
+              "precision=fp32", "eval_batch_size=8"]
+    one = _run(common)
+    two = _run(common + ["gpus=2", "backend=gloo"])
+    for k in ("r1", "r5", "r10", "mr"):
+        assert one[k] == two[k], (k, one, two)
+    assert abs(one["loss/val"] - two["loss/val"]) < 1e-5
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """`python bench.py --gpus 2 --backend gloo`: the bench launches its own ranks, shards the clips, gathers embeddings
+    and ranks, and prints one line whose whole-job value counts both ranks' clips."""
+    line = _run(["bench.py", "--gpus", "2", "--backend", "gloo", "--clips", "16", "--frames", "2", "--steps", "1",
+                 "--warmup", "1", "--no-bf16-mode", "--no-cpu-baseline", "--cpu-sample-clips", "8"])
+    assert line["n_gpus"] == 2 and line["dtype"] == "fp32" and line["scaling"] == "weak"
+    assert line["retrieval"]["n"] == 32 and line["value"] > 0
+    assert line["retrieval"]["r1"] > 0.2  # rank 0's captions are planted on their clips; chance would be 1/32

@@ -12,7 +12,11 @@ stream -> doubled; WRITE_SIZE is exact for 16-byte-per-lane stores; both are in 
 import argparse
 import csv
 import json
+import os
+import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_dispatch(path, needle, min_us):
@@ -59,6 +63,8 @@ def main():
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950), KiB units",
            "shape": [M, N, K], "precision": a.precision, "epilogue": a.epilogue,
            "algorithmic_bytes_per_launch": (M * K + N * K + M * N) * esz}
+    from fitclip_amd.build import source_fingerprint
+    res["source_fingerprint"] = source_fingerprint()  # bench.py refuses the file once the kernel sources change
     if a.sq:
         s, durs = per_dispatch(a.sq, a.kernel, a.min_us)
         sq = {k: round(mean(v)) for k, v in s.items()}

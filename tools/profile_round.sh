@@ -1,31 +1,44 @@
 #!/bin/bash
 # Reproduces the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun, from the repo root):
-#   tools/profile_round.sh r01
-# 1. kernel trace + stats of the default bench command (CPU leg off);  2./3. separate PMC passes (FETCH_SIZE,
-# WRITE_SIZE) and 4. an SQ pass for the dominant kernel.  Raw output goes to gpurun_out/prof_*; summaries to profiles/.
+#   tools/profile_round.sh r02 fp32        # the headline precision
+#   tools/profile_round.sh r02 bf16        # the secondary mode
+# 1. kernel trace + stats of the bench command for that precision (CPU leg and the other precision off);
+# 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) and 4. an SQ pass for the dominant kernel (c_fc + QuickGELU GEMM).
+# Raw output goes to gpurun_out/prof_*; summaries to profiles/ AND gpurun_out/profiles_<tag>/ (the latter travels back).
+# The program stays directly after `--` (no env / bash -c hop: the profiler has already initialised the GPU).
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
+prec=${2:-fp32}
 repo=$(pwd)
 out=$repo/gpurun_out
-mkdir -p "$out"
+keep=$out/profiles_${tag}
+mkdir -p "$out" "$keep"
 cd /tmp && export TMPDIR=/tmp
 # The profiled runs keep the two towers on ONE stream (FITCLIP_OVERLAP_TEXT=0): with the default two-stream forward the
 # text-tower kernels overlap the visual tower's LayerNorm / attention kernels in time, and a per-kernel duration then
 # no longer describes a kernel that owns the chip.  The dominant GEMM is not affected either way (nothing fits next to
 # a persistent GEMM workgroup).
 export FITCLIP_OVERLAP_TEXT=0
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace" -o bench -- python3 "$repo/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/prof_trace.json" 2> "$out/prof_trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$out/prof_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/prof_write" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$out/prof_write.err"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/prof_sq" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$out/prof_sq.err" || echo "SQ pass failed (counters may need separate passes)"
+if [ "$prec" = fp32 ]; then kern=gemm_pipelined_kernelIfLi256ELi256ELi2ELi4ELi1; minus=2000; steps=3; else kern=gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1; minus=250; steps=5; fi
+common="--precision $prec --no-bf16-mode --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup 2 $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
+echo "trace pass done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_fetch_$prec.err"
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/prof_write_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_write_$prec.err"
+echo "write pass done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/prof_sq_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_sq_$prec.err" || echo "SQ pass failed (counters may need separate passes)"
+echo "sq pass done"
 cd "$repo"
-find "$out/prof_trace" -name "*kernel_stats.csv" -exec cp {} "profiles/${tag}_final_bench_kernel_stats.csv" \;
-trace=$(find "$out/prof_trace" -name "*kernel_trace.csv" | head -1)
-python tools/trace_summary.py "$trace" > "profiles/${tag}_final_bench_trace_summary.txt"
-cp "$out/prof_trace.json" "profiles/${tag}_final_bench_under_rocprof.json"
-f=$(find "$out/prof_fetch" -name "*counter_collection.csv" | head -1)
-w=$(find "$out/prof_write" -name "*counter_collection.csv" | head -1)
-q=$(find "$out/prof_sq" -name "*counter_collection.csv" | head -1)
-python tools/pmc_traffic.py --fetch "$f" --write "$w" ${q:+--sq "$q"} --kernel gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1 \
-  --min-us 250 --shape 100864 3072 768 --precision bf16 --epilogue bias_quickgelu --out "profiles/traffic_${tag}.json"
-cp "profiles/traffic_${tag}.json" "$out/"
+find "$out/prof_trace_$prec" -name "*kernel_stats.csv" -exec cp {} "$keep/${tag}_bench_${prec}_kernel_stats.csv" \;
+trace=$(find "$out/prof_trace_$prec" -name "*kernel_trace.csv" | head -1)
+python3 tools/trace_summary.py "$trace" > "$keep/${tag}_bench_${prec}_trace_summary.txt"
+cp "$out/prof_trace_$prec.json" "$keep/${tag}_bench_${prec}_under_rocprof.json"
+f=$(find "$out/prof_fetch_$prec" -name "*counter_collection.csv" | head -1)
+w=$(find "$out/prof_write_$prec" -name "*counter_collection.csv" | head -1)
+q=$(find "$out/prof_sq_$prec" -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_traffic.py --fetch "$f" --write "$w" ${q:+--sq "$q"} --kernel $kern \
+  --min-us $minus --shape 100864 3072 768 --precision $prec --epilogue bias_quickgelu --out "$keep/traffic_${tag}_${prec}.json"
+cp "$keep"/* profiles/
+# the raw traces are large: keep only the summaries for the trip back
+rm -rf "$out/prof_trace_$prec" "$out/prof_fetch_$prec" "$out/prof_write_$prec" "$out/prof_sq_$prec"

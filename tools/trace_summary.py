@@ -20,10 +20,13 @@ def main():
     M = chunk * 197
     shapes = {"qkv": (2304, 768), "out_proj": (768, 768), "c_fc": (3072, 768), "c_proj": (768, 3072)}
     labelled = []
+    fp32 = False  # the exact-fp32 mode runs the same kernels ~8x longer: other duration cuts
     for r in rows:
         name = r["Kernel_Name"]
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        if "gemm_pipelined_kernel" in name and "DF16b" in name and "Li256ELi256ELi2ELi4ELi0E" in name:
+        if "gemm_pipelined_kernelIf" in name:
+            fp32 = True
+        if "gemm_pipelined_kernel" in name and "Li256ELi256ELi2ELi4ELi0E" in name:
             label = "bias_gemm"
         elif "gemm_pipelined_kernel" in name and "Li256ELi256ELi2ELi4ELi1E" in name:
             label = "c_fc"
@@ -39,7 +42,9 @@ def main():
             label = "other"
         labelled.append([label, dur])
     # visual-tower launches of the pipelined GEMMs run for > 80 us at chunk >= 256 frames; the text tower's for < 60 us
-    cut = 70.0
+    # (fp32: visual >= 900 us, text <= 350 us)
+    cut = 600.0 if fp32 else 70.0
+    cut_small = 100.0 if fp32 else 40.0
     seq = 0
     for item in labelled:
         if item[0] == "bias_gemm":
@@ -50,7 +55,7 @@ def main():
                 seq += 1
         elif item[0] == "c_fc" and item[1] < cut:
             item[0] = "text gemm"
-        elif item[0] in ("attention", "add_layernorm") and item[1] < 40.0:
+        elif item[0] in ("attention", "add_layernorm") and item[1] < cut_small:
             item[0] = "text " + item[0]
     agg = defaultdict(list)
     for label, dur in labelled:
