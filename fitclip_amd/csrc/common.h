@@ -41,6 +41,7 @@ enum Epilogue : int {
   EPI_RESID_F32 = 2,  // C(f32) += acc + bias          (residual stream update, in place)
   EPI_PATCH_F32 = 3,  // C(f32)[m + m/P + 1] = acc + pos[(m % P) + 1]   (patch embedding into the token stream)
   EPI_STORE_F32 = 4,  // C(f32) = alpha * acc (+ bias if given)
+  EPI_DGELU_T = 5,    // C(T)   = acc * quickgelu'(aux(T)[m, n])   (backward of c_fc's activation; aux laid out as C)
 };
 
 struct GemmArgs {
@@ -48,7 +49,7 @@ struct GemmArgs {
   const void* W;      // T [N, ldw]
   const float* bias;  // [N] or nullptr
   void* C;            // [M(+), ldc]
-  const float* aux;   // EPI_PATCH_F32: positional embedding [P + 1, N]
+  const float* aux;   // EPI_PATCH_F32: positional embedding [P + 1, N]; EPI_DGELU_T: pre-activation, T [M, ldc]
   float alpha;        // EPI_STORE_F32
   int M, N, K;
   int lda, ldw, ldc;  // in elements

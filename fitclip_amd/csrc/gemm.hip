@@ -79,7 +79,7 @@ bool pipelined_ok(const GemmArgs& a) {
 template <typename T>
 int resolve_tile(int epi, const GemmArgs& a, int tile) {
   if (tile != 0) return tile;
-  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T;
+  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || (epi == EPI_DGELU_T && sizeof(T) == 4);
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
   return t256 >= 512 ? 2 : 1;
@@ -88,7 +88,7 @@ int resolve_tile(int epi, const GemmArgs& a, int tile) {
 // tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (BIAS_T / GELU_T only)
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
-  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T;
+  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
     if constexpr (kHasPipelined) {
@@ -110,6 +110,7 @@ int launch_epi(int epi, const GemmArgs& a, int tile, hipStream_t stream) {
     case EPI_RESID_F32: return launch_tile<T, EPI_RESID_F32>(a, tile, stream);
     case EPI_PATCH_F32: return launch_tile<T, EPI_PATCH_F32>(a, tile, stream);
     case EPI_STORE_F32: return launch_tile<T, EPI_STORE_F32>(a, tile, stream);
+    case EPI_DGELU_T: return launch_tile<T, EPI_DGELU_T>(a, tile, stream);
   }
   return fail(FC_EINVAL, "gemm: unknown epilogue %d", epi);
 }
@@ -130,7 +131,9 @@ int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStr
     return fail(FC_EINVAL, "gemm: lda=%d / ldw=%d must cover K and keep rows 16-byte aligned", a.lda, a.ldw);
   if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm: ldc=%d", a.ldc);
   if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return fail(FC_EINVAL, "gemm: unaligned operand");
-  if (epilogue != EPI_STORE_F32 && epilogue != EPI_PATCH_F32 && !a.bias) return fail(FC_EINVAL, "gemm: bias missing");
+  if (epilogue != EPI_STORE_F32 && epilogue != EPI_PATCH_F32 && epilogue != EPI_DGELU_T && !a.bias)
+    return fail(FC_EINVAL, "gemm: bias missing");
+  if (epilogue == EPI_DGELU_T && (!a.aux || ((uintptr_t)a.aux & 15))) return fail(FC_EINVAL, "gemm: dgelu epilogue needs aux");
   if (epilogue == EPI_PATCH_F32 && (!a.aux || a.P <= 0)) return fail(FC_EINVAL, "gemm: patch epilogue needs pos/P");
   if (tile < 0 || tile > 3) return fail(FC_EINVAL, "gemm: tile=%d", tile);
   return precision == PREC_BF16 ? launch_epi<bf16>(epilogue, a, tile, stream)

@@ -58,6 +58,17 @@ __device__ __forceinline__ f32x4 quick_gelu_fast4(f32x4 x) {
   return f32x4{rl[0], rl[1], rh[0], rh[1]};
 }
 __device__ __forceinline__ float quick_gelu_exact(float x) { return x / (1.f + expf(-1.702f * x)); }
+// d/dx [x * sigmoid(1.702 x)] = s * (1 + 1.702 x (1 - s)),  s = sigmoid(1.702 x)   (slip.py:359-361 differentiated)
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+  const float s = 1.f / (1.f + expf(-1.702f * x));
+  return s * (1.f + 1.702f * x * (1.f - s));
+}
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{static_cast<float>(v[0]), static_cast<float>(v[1]), static_cast<float>(v[2]), static_cast<float>(v[3])};
+}
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { using type = bf16x8; };
@@ -221,6 +232,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
         v += *reinterpret_cast<const f32x4*>(g.bias + n);
         v += *reinterpret_cast<const f32x4*>(p);
         store4<float>(p, v);
+      } else if constexpr (EPI == EPI_DGELU_T) {
+        const f32x4 pre = load4<T>(reinterpret_cast<const T*>(g.aux) + orow * g.ldc + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(pre[e]);
+        store4<T>(reinterpret_cast<T*>(g.C) + orow * g.ldc + n, v);
       } else {
         if constexpr (EPI == EPI_GELU_T) {
 #pragma unroll
@@ -313,7 +329,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int OFF_BIAS = OFF_STG + (kStaged ? NW * PATCH : 0);  // 2 x 1 KiB
   constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
-  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T, "epilogue");
+  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && !kStaged), "epilogue");
   static_assert(LPW + NST < 64, "vmcnt range");
   using FragT = typename Frag<T>::type;
 
@@ -605,6 +621,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
             if constexpr (EPI == EPI_GELU_T) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
+            }
+            if constexpr (EPI == EPI_DGELU_T) {
+              // (these loads make hipcc drain vmcnt before the stores; the counted wait of the next tile stays valid,
+              // it only asks for "at most NST operations still in flight")
+              if (interior || (m < g.M && n < g.N)) {
+                const f32x4 pre = load4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)m * g.ldc + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(pre[e]);
+              }
             }
             if (interior || (m < g.M && n < g.N))
               __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<T*>(g.C) + (size_t)m * g.ldc + n));

@@ -550,7 +550,7 @@ def test_data_writes_are_picked_up_after_invalidate_weights(tiny_state_dict):
         with torch.no_grad():
             enc.model.visual.proj.data.mul_(-1.0)
             enc.model.text_projection.data.mul_(-1.0)
-            enc.model.visual.transformer.resblocks[0].mlp.c_fc.weight.data.mul_(0.5)
+            getattr(enc.model.visual.transformer.resblocks, "0").mlp.c_fc.weight.data.mul_(0.5)
         enc.model.invalidate_weights()
         v1, t1 = enc.encode_video(video), enc.encode_text({"input_ids": ids})
         assert torch.allclose(t1, -t0, atol=1e-6), precision          # the transposed projection copy was rebuilt

@@ -7,6 +7,7 @@ trace minus the summed kernel time).
     python tools/trace_summary.py <..._kernel_trace.csv> [frames_per_chunk]
 """
 import csv
+import re
 import statistics
 import sys
 from collections import defaultdict
@@ -24,11 +25,13 @@ def main():
     for r in rows:
         name = r["Kernel_Name"]
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        if "gemm_pipelined_kernelIf" in name:
+        if "gemm_pipelined_kernelIf" in name or "gemm_pipelined_kernel<float" in name:
             fp32 = True
-        if "gemm_pipelined_kernel" in name and "Li256ELi256ELi2ELi4ELi0E" in name:
+        # rocprofv3 prints mangled or demangled names depending on its version: accept both spellings
+        pipelined = re.search(r"gemm_pipelined_kernel<[^,]+, 256, 256, 2, 4, (\d),", name)
+        if "gemm_pipelined_kernel" in name and ("Li256ELi256ELi2ELi4ELi0E" in name or (pipelined and pipelined.group(1) == "0")):
             label = "bias_gemm"
-        elif "gemm_pipelined_kernel" in name and "Li256ELi256ELi2ELi4ELi1E" in name:
+        elif "gemm_pipelined_kernel" in name and ("Li256ELi256ELi2ELi4ELi1E" in name or (pipelined and pipelined.group(1) == "1")):
             label = "c_fc"
         elif "attn_" in name:
             label = "attention"
