@@ -15,7 +15,7 @@ _CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("FITCLIP_HIP_LIB", _CSRC / "libfitclip_hip.so"))
 
 PREC_F32, PREC_BF16 = 0, 1
-EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32 = range(5)
+EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_DGELU_T = range(6)
 
 
 class FitclipHipError(RuntimeError):
@@ -65,6 +65,27 @@ SIGNATURES = {
     "fc_add_layernorm": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fc_attention": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "fc_convert": (_i32, [_vp, _vp, _i32, _sz, _vp]),
+    "fc_set_grad": (_i32, [_vp, C.c_char_p, _vp]),
+    "fc_train_weights_bytes": (_sz, [_vp]),
+    "fc_train_prepare": (_i32, [_vp, _vp, _sz, _vp]),
+    "fc_train_arena_bytes": (_sz, [_vp, _i32, _i32]),
+    "fc_train_scratch_bytes": (_sz, [_vp, _i32, _i32]),
+    "fc_encode_image_train": (_i32, [_vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "fc_encode_text_train": (_i32, [_vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "fc_encode_image_backward": (_i32, [_vp, _vp, _i32, _vp, _sz, _vp, _sz, _i32, _vp]),
+    "fc_encode_text_backward": (_i32, [_vp, _vp, _vp, _i32, _vp, _sz, _vp, _sz, _i32, _vp]),
+    "fc_pool_normalize_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "fc_nce_loss_backward": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp]),
+    "fc_kd_loss_backward": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "fc_kd_teacher_scale_grad": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "fc_gemm_tn_scratch_bytes": (_sz, [_i32, _i32, _i32]),
+    "fc_gemm_tn": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp, _sz, _vp]),
+    "fc_attention_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "fc_layernorm_backward_scratch_bytes": (_sz, [_i32]),
+    "fc_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "fc_dot": (_i32, [_vp, _vp, _sz, _f32, _f32, _vp, _vp]),
+    "fc_transpose": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "fc_adamw": (_i32, [_vp, _vp, _vp, _vp, _sz, _f64, _f64, _f64, _f64, _f64, _i32, _vp]),
     "fc_profile_enable": (_i32, [_vp, _i32]),
     "fc_profile_select": (_i32, [_vp, C.c_uint32, C.c_uint32]),
     "fc_profile_reset": (_i32, [_vp]),

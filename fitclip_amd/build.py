@@ -13,8 +13,9 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 REPO = CSRC.parent.parent
 LIB = CSRC / "libfitclip_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "rowops.hip", "score.hip"]
-HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", REPO / "include" / "fitclip_hip.h"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
+           "train.hip"]
+HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "handle.h", REPO / "include" / "fitclip_hip.h"]
 ARCH = "gfx950"
 
 

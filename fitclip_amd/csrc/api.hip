@@ -2,6 +2,7 @@
 // sequence the HIP kernels of this directory on the caller's stream.  No device allocation, no synchronisation.
 #include "../../include/fitclip_hip.h"
 #include "common.h"
+#include "handle.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -40,53 +41,7 @@ hipError_t raise_dynamic_lds(const void* kernel, int bytes) {
   return e;
 }
 
-namespace {
-
-struct WeightSlot {
-  std::vector<int64_t> shape;
-  const float* ptr = nullptr;
-};
-
-struct Block {
-  const float *ln1_w, *ln1_b, *in_b, *out_b, *ln2_w, *ln2_b, *fc_b, *proj_b;
-  const void *in_w, *out_w, *fc_w, *proj_w;  // element type T of the handle's precision, [N, K]
-};
-
-struct Tower {
-  std::vector<Block> blocks;
-};
-
-inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-
-}  // namespace
 }  // namespace fc
-
-struct fc_handle {
-  fc_config cfg{};
-  int esz = 4;  // bytes per activation / GEMM-weight element
-  std::vector<std::string> names;
-  std::map<std::string, fc::WeightSlot> slots;
-  bool packed = false;
-  fc::Tower vis, txt;
-  const void *conv_w = nullptr, *vproj_t = nullptr, *tproj_t = nullptr;
-  // profiling
-  std::vector<hipEvent_t> ev;
-  std::vector<fc_prof_record> recs;
-  int prof_cap = 0;
-  unsigned prof_kinds = ~0u, prof_epis = ~0u;  // fc_profile_select masks
-
-  int vheads() const { return cfg.vision_width / 64; }
-  int grid() const { return cfg.image_resolution / cfg.vision_patch_size; }
-  int patches() const { return grid() * grid(); }
-  int vtokens() const { return patches() + 1; }
-  int patch_k() const { return 3 * cfg.vision_patch_size * cfg.vision_patch_size; }
-  // the patch-embed GEMM's K: 3 p^2 padded to the kernel's K-tile (64 bf16 / 32 f32 elements); ViT-L/14: 588 -> 640
-  int patch_kp() const {
-    const int gran = cfg.precision == FC_PREC_BF16 ? 64 : 32;
-    return (patch_k() + gran - 1) / gran * gran;
-  }
-  const float* w(const std::string& n) const { return slots.at(n).ptr; }
-};
 
 namespace fc {
 namespace {
@@ -381,6 +336,7 @@ int fc_set_weight(fc_handle* h, const char* name, const float* dev, const int64_
   if (!dev || ((uintptr_t)dev & 15)) return fail(FC_EINVAL, "fc_set_weight: \"%s\" must be a 16-byte aligned device pointer", name);
   it->second.ptr = dev;
   h->packed = false;
+  h->train_ready = false;
   return FC_OK;
 }
 
@@ -436,6 +392,7 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
   h->vproj_t = gw("visual.proj");
   h->tproj_t = gw("text_projection");
   h->packed = true;
+  h->train_ready = false;  // the transposed copies of fc_train_prepare belong to the previous weights
   return FC_OK;
 }
 

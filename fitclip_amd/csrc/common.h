@@ -80,7 +80,7 @@ int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tok
                           hipStream_t stream);
 int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
-                         int write_x, int delta_compact, hipStream_t stream);
+                         int write_x, int delta_compact, hipStream_t stream, float* x_out = nullptr);
 // dst[i] = src row (idx ? idx[i] : i * step), rows of row_bytes bytes (multiple of 16)
 int launch_gather_rows(const void* src, const int* idx, long step, void* dst, int n, int row_bytes, hipStream_t stream);
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, int Kp,
@@ -104,6 +104,44 @@ int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target
                  int32_t* ranks, hipStream_t stream);
 int launch_nce_loss(const float* scores, int n, float* out, float* ws, hipStream_t stream);
 int launch_kd_loss(const float* scores, const float* teacher, int n, float* out, float* ws, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------- training step
+// attention backward (attention_bwd.hip); qkv / o are the forward's input / output, d_o the gradient of o
+int launch_attention_backward(int precision, const void* qkv, const void* o, const void* d_o, void* dqkv, int n_seq,
+                              int S, int heads, int causal, hipStream_t stream);
+// C[N1, N2] = beta C + alpha sum_m A[m, N1] B[m, N2]  (wgrad.hip; fp32).  a_skip > 0: A row m lives at m + m / a_skip + 1
+size_t gemm_tn_scratch_bytes(int M, int N1, int N2);
+int launch_gemm_tn(const float* A, const float* B, int M, int N1, int N2, int lda, int ldb, int a_skip, float alpha,
+                   float beta, float* C, int ldc, float* scratch, size_t scratch_bytes, const float* zeros,
+                   hipStream_t st);
+int launch_reduce_partials(const float* P, int splits, int rows, int cols, float* C, int ldc, float alpha, float beta,
+                           hipStream_t st);
+size_t colsum_scratch_bytes(int rows, int cols);
+int launch_colsum(const void* X, int kind, long ldx, int rows, int cols, float* out, float beta, float* scratch,
+                  size_t scratch_bytes, hipStream_t st);
+// backward.hip
+size_t layernorm_bwd_scratch_bytes(int D);
+int launch_layernorm_backward(const float* x, long x_stride, const int* gather, const void* dy, int dy_kind,
+                              long dy_stride, int dy_compact, const float* gamma, float* out, long out_stride,
+                              int accumulate, int rows, int D, float* dgamma, float* dbeta, float beta_acc,
+                              float* scratch, size_t scratch_bytes, hipStream_t st);
+int launch_quickgelu(const void* in, void* out, int kind, size_t n, hipStream_t st);
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
+                 double wd, int step, hipStream_t st);
+int launch_pool_normalize_backward(const float* z, const float* dout, float* dz, int n_clips, int frames, int dim,
+                                   hipStream_t st);
+int launch_loss_backward(const float* scores, const float* teacher, int n, float coef, float* dscores, float* ws,
+                         hipStream_t st);
+int launch_dot(const float* a, const float* b, size_t n, float alpha, float beta, float* out, hipStream_t st);
+int launch_kd_teacher_scale_grad(const float* scores, const float* teacher, int n, float* out, float* ws,
+                                 hipStream_t st);
+// sums[t, :] = sum_i g[i * S + t, :] into scratch (S * D floats), then out_pos = beta out_pos + sums and, if given,
+// out_row0 = beta out_row0 + sums[0]
+int launch_seq_sum(const float* g, int n_seq, int S, int D, float* out_pos, float* out_row0, float beta, float* scratch,
+                   size_t scratch_bytes, hipStream_t st);
+int launch_token_scatter_add(const int64_t* ids, const float* g, float* dtok, int rows, int D, int vocab,
+                             hipStream_t st);
+int launch_fill_cls(float* x, const float* cls, const float* pos0, int n_seq, int S, int D, hipStream_t st);
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

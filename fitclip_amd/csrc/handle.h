@@ -1,0 +1,62 @@
+// Internal: the handle behind the C ABI (shared by api.hip: inference, and train.hip: the KD training step).
+#pragma once
+#include "../../include/fitclip_hip.h"
+#include "common.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace fc {
+
+struct WeightSlot {
+  std::vector<int64_t> shape;
+  const float* ptr = nullptr;
+  float* grad = nullptr;  // fc_set_grad (training only)
+};
+
+struct Block {
+  const float *ln1_w, *ln1_b, *in_b, *out_b, *ln2_w, *ln2_b, *fc_b, *proj_b;
+  const void *in_w, *out_w, *fc_w, *proj_w;  // element type T of the handle's precision, [N, K]
+  // training: transposed copies [K, N] for the dgrad GEMMs (fc_train_prepare)
+  const void *in_wT = nullptr, *out_wT = nullptr, *fc_wT = nullptr, *proj_wT = nullptr;
+};
+
+struct Tower {
+  std::vector<Block> blocks;
+};
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace fc
+
+struct fc_handle {
+  fc_config cfg{};
+  int esz = 4;  // bytes per activation / GEMM-weight element
+  std::vector<std::string> names;
+  std::map<std::string, fc::WeightSlot> slots;
+  bool packed = false;
+  fc::Tower vis, txt;
+  const void *conv_w = nullptr, *vproj_t = nullptr, *tproj_t = nullptr;
+  // training
+  bool train_ready = false;
+  const float* zeros = nullptr;  // >= 16 KiB of zeros in the training weight arena (null bias / TN tail rows)
+  // profiling
+  std::vector<hipEvent_t> ev;
+  std::vector<fc_prof_record> recs;
+  int prof_cap = 0;
+  unsigned prof_kinds = ~0u, prof_epis = ~0u;  // fc_profile_select masks
+
+  int vheads() const { return cfg.vision_width / 64; }
+  int grid() const { return cfg.image_resolution / cfg.vision_patch_size; }
+  int patches() const { return grid() * grid(); }
+  int vtokens() const { return patches() + 1; }
+  int patch_k() const { return 3 * cfg.vision_patch_size * cfg.vision_patch_size; }
+  // the patch-embed GEMM's K: 3 p^2 padded to the kernel's K-tile (64 bf16 / 32 f32 elements); ViT-L/14: 588 -> 640
+  int patch_kp() const {
+    const int gran = cfg.precision == FC_PREC_BF16 ? 64 : 32;
+    return (patch_k() + gran - 1) / gran * gran;
+  }
+  const float* w(const std::string& n) const { return slots.at(n).ptr; }
+  float* grad(const std::string& n) const { return slots.at(n).grad; }
+};

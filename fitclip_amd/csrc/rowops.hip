@@ -173,14 +173,15 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             long y_stride, int rows, int write_x,
-                                                            int delta_compact) {
+                                                            int delta_compact, float* __restrict__ x_out) {
   static_assert(D % 256 == 0 || D == 128, "width");
   constexpr int V4 = D / 256, REM = (D % 256) / 64;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
     const long src = gather ? gather[row] : row;
-    float* xr = x + src * x_stride;
+    const float* xr = x + src * x_stride;
+    float* xw = (x_out ? x_out : x) + src * x_stride;  // training keeps every block's input: the sum goes elsewhere
     const T* dr = delta + (delta_compact ? (long)row : src) * d_stride;
     f32x4 v[V4 > 0 ? V4 : 1];
     float s[REM > 0 ? REM : 1];
@@ -196,14 +197,14 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
       } else {
         v[i] += *reinterpret_cast<const f32x4*>(dr + c);
       }
-      if (write_x) *reinterpret_cast<f32x4*>(xr + c) = v[i];
+      if (write_x) *reinterpret_cast<f32x4*>(xw + c) = v[i];
       sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
       const int c = V4 * 256 + i * 64 + lane;
       s[i] = xr[c] + static_cast<float>(dr[c]);
-      if (write_x) xr[c] = s[i];
+      if (write_x) xw[c] = s[i];
       sum += s[i];
     }
     const float mean = wave_sum(sum) * (1.f / D);
@@ -244,16 +245,16 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
 template <typename T>
 int add_layernorm_dispatch(float* x, long xs, const void* delta, long ds, const int* gather, const float* g,
                            const float* b, void* y, long ys, int rows, int D, int write_x, int delta_compact,
-                           hipStream_t st) {
+                           float* x_out, hipStream_t st) {
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   const T* dl = reinterpret_cast<const T*>(delta);
   T* yo = reinterpret_cast<T*>(y);
   switch (D) {
-    case 128: hipLaunchKernelGGL((add_layernorm_kernel<128, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
-    case 256: hipLaunchKernelGGL((add_layernorm_kernel<256, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
-    case 512: hipLaunchKernelGGL((add_layernorm_kernel<512, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
-    case 768: hipLaunchKernelGGL((add_layernorm_kernel<768, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
-    case 1024: hipLaunchKernelGGL((add_layernorm_kernel<1024, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact); break;
+    case 128: hipLaunchKernelGGL((add_layernorm_kernel<128, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
+    case 256: hipLaunchKernelGGL((add_layernorm_kernel<256, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
+    case 512: hipLaunchKernelGGL((add_layernorm_kernel<512, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
+    case 768: hipLaunchKernelGGL((add_layernorm_kernel<768, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
+    case 1024: hipLaunchKernelGGL((add_layernorm_kernel<1024, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
     default: return fail(FC_EINVAL, "add_layernorm: unsupported width %d", D);
   }
   FC_CHECK_LAUNCH("add_layernorm");
@@ -567,16 +568,17 @@ int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tok
 
 int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stride, const int* gather,
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
-                         int write_x, int delta_compact, hipStream_t stream) {
+                         int write_x, int delta_compact, hipStream_t stream, float* x_out) {
   if (rows <= 0) return FC_OK;
   const int esz = kind == 1 ? 2 : 4;
   if ((x_stride % 4) || (d_stride * esz) % 8 || (y_stride * esz) % 8 ||
       (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta) & 15))
     return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned");
+  if (x_out && ((uintptr_t)x_out & 15)) return fail(FC_EINVAL, "add_layernorm: x_out must be 16-byte aligned");
   return kind == 1 ? add_layernorm_dispatch<bf16>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows,
-                                                  D, write_x, delta_compact, stream)
+                                                  D, write_x, delta_compact, x_out, stream)
                    : add_layernorm_dispatch<float>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows,
-                                                   D, write_x, delta_compact, stream);
+                                                   D, write_x, delta_compact, x_out, stream);
 }
 
 int launch_im2col(const float* frames, void* patches, int out_kind, int n, int res, int patch, int Kp,

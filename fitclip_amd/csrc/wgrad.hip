@@ -136,9 +136,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_tn_kernel(const TnArgs g) {
 }
 
 // C[r, c] = beta * C[r, c] + alpha * sum_s P[s][r * cols + c]      (fixed summation order: deterministic)
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ P, int splits, size_t plane,
-                                                              int cols, float* __restrict__ C, int ldc, float alpha,
-                                                              float beta) {
+// (P and C may alias when C is plane 0 of P: every element is read before it is written, by the same thread)
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* P, int splits, size_t plane, int cols,
+                                                              float* C, int ldc, float alpha, float beta) {
   const size_t n4 = plane / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 s = *reinterpret_cast<const f32x4*>(P + i * 4);

@@ -71,6 +71,20 @@ def all_gather_many(tensors: Sequence[torch.Tensor], counts: Sequence[int]) -> L
     return [g.contiguous() for g in gathered.split(widths, dim=1)]
 
 
+def all_reduce_sum_(t: torch.Tensor, async_op: bool = False):
+    """In-place sum over the ranks (gradient exchange of the training step: RCCL all-reduce of a slice of the flat
+    gradient buffer).  Returns the work handle when `async_op` (None if there is nothing to wait for)."""
+    rank, world_size = world()
+    if world_size == 1 or t.numel() == 0:
+        return None
+    if t.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal of the multi-rank path: stage through the host
+        host = t.cpu()
+        dist.all_reduce(host)
+        t.copy_(host)
+        return None
+    return dist.all_reduce(t, async_op=async_op) if async_op else dist.all_reduce(t)
+
+
 def metrics_from_ranks(ranks: np.ndarray) -> Dict[str, float]:
     """R@1/5/10 = fraction of ranks < k (torchmetrics Recall(top_k), text_video_retrieval.py:21); MedianRank =
     lower-middle median + 1 (torch.median semantics, aligner/metrics.py:33-36)."""

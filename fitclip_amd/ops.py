@@ -160,6 +160,28 @@ def similarity(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Te
     return buf[:, :nb]
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+            beta: float = 0.0) -> torch.Tensor:
+    """out[N1, N2] = beta * out + alpha * a[M, N1]^T @ b[M, N2] in exact fp32 (weight gradients dW = dY^T X, and the
+    gradients of the similarity matrix w.r.t. the embeddings)."""
+    _dev(a, "a", torch.float32), _dev(b, "b", torch.float32)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError(f"gemm_tn needs [M, N1] and [M, N2], got {tuple(a.shape)} and {tuple(b.shape)}")
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta needs an `out` to accumulate into")
+        out = torch.empty((N1, N2), dtype=torch.float32, device=a.device)
+    _dev(out, "out", torch.float32)
+    lib = _lib.load()
+    scratch = torch.empty(lib.fc_gemm_tn_scratch_bytes(M, N1, N2), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.fc_gemm_tn(a.data_ptr(), b.data_ptr(), M, N1, N2, N1, N2, alpha, beta, out.data_ptr(), N2,
+                                  scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "fc_gemm_tn")
+    return out
+
+
 def ranks(scores: torch.Tensor, target_offset: int = 0) -> torch.Tensor:
     """Position of column (i + target_offset) in the stable descending order of row i (aligner/metrics.py:16-20)."""
     if scores.device.type != "cuda" or scores.dtype != torch.float32 or scores.stride(1) != 1:

@@ -1,0 +1,344 @@
+"""The KD fine-tuning step on the HIP path: what `TeacherStudentLightningModule.training_step / training_step_end /
+optimizer_step` do through autograd + `torch.optim.AdamW` + DDP in the reference
+(`aligner/teacher_student.py:93-183`, `aligner/video_text_module.py:55-97`, `aligner/cli.py:129`,
+`config/trainer.yaml:21-23`), as explicit forward / backward / update calls into libfitclip_hip.so.
+
+    student = ClipVideoTextEncoder(build_clip(sd_student, precision="fp32", device="cuda"))
+    teacher = ClipVideoTextEncoder(build_clip(sd_teacher, precision="bf16", device="cuda"))   # frozen: any precision
+    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=3e-6)
+    loss = module.fit_step({"video_student": ..., "text_student": {"input_ids": ...}, "video_teacher": ...,
+                            "text_teacher": {"input_ids": ...}, "dataset": ["labeled"] * a + ["unlabeled"] * b})
+
+`StudentTrainer` owns the native training state of one CLIP student: parameters, gradients and the two AdamW moments
+live in four flat fp32 buffers (every `nn.Parameter` of the model is a view into the first, its `.grad` a view into the
+second), so the optimiser is ONE kernel launch and the data-parallel gradient exchange is an all-reduce of slices of one
+buffer.  Only fp32 models train (the reference trains in float32: Trainer precision 32).
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from . import distributed as D
+from . import ops
+from .encoder import ClipVideoTextEncoder
+from .retrieval import TeacherStudentModule
+
+_ALIGN = 64  # floats: every parameter starts on a 256-byte boundary of the flat buffers
+
+
+class StudentTrainer:
+    def __init__(self, encoder: ClipVideoTextEncoder, lr: float = 3e-6, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 1e-2, max_frames_per_pass: int = 1024,
+                 max_texts_per_pass: int = 4096) -> None:
+        model = encoder.model
+        if model.precision not in ("fp32", "f32", "float32"):
+            raise ValueError("only precision='fp32' models train (the reference trains in float32)")
+        self.encoder, self.model = encoder, model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_frames, self.max_texts = max_frames_per_pass, max_texts_per_pass
+        self.step_count = 0
+        dev = model._device()
+        if dev.type != "cuda":
+            raise _lib.FitclipHipError("move the student to the ROCm device before training (no CPU fallback)")
+        named = model._named_weights()
+        offsets, total = {}, 0
+        for name, p in named:
+            offsets[name] = total
+            total += -(-p.numel() // _ALIGN) * _ALIGN
+        self.params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.offsets, self.total = offsets, total
+        with torch.no_grad():
+            for name, p in named:
+                o, n = offsets[name], p.numel()
+                view = self.params[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                                   # the module's parameters ARE the flat buffer from now on
+                p.requires_grad_(True)
+                p.grad = self.grads[o:o + n].view(p.shape)
+        # text-tower parameters sit at both ends of named_parameters(): three slices for the bucketed gradient exchange
+        vis = [offsets[n] for n, _ in named if n.startswith("visual.")]
+        after = [offsets[n] for n, _ in named if not n.startswith("visual.") and offsets[n] > max(vis)]
+        self.visual_span = (min(vis), min(after) if after else total)
+        model.invalidate_weights()
+        self._wt_arena = None
+        self._state: Optional[Dict[str, Any]] = None
+        self._scratch: Dict[int, torch.Tensor] = {}
+        self._bind()
+
+    # ------------------------------------------------------------------------------------------------- native state
+    def _bind(self) -> None:
+        """(Re)packs the weights, hands the gradient views to the handle and refreshes the transposed weight copies
+        the dgrad GEMMs read.  Needed once, and again after every parameter update."""
+        lib = _lib.load()
+        rt = self.model._ensure_ready()
+        with torch.cuda.device(self.params.device):
+            for name, p in self.model._named_weights():
+                _lib.check(lib.fc_set_grad(rt.handle, name.encode(), p.grad.data_ptr()), f"fc_set_grad({name})")
+            need = lib.fc_train_weights_bytes(rt.handle)
+            if self._wt_arena is None or self._wt_arena.numel() < need:
+                self._wt_arena = torch.empty(need, dtype=torch.uint8, device=self.params.device)
+            _lib.check(lib.fc_train_prepare(rt.handle, self._wt_arena.data_ptr(), self._wt_arena.numel(),
+                                            _lib.current_stream()), "fc_train_prepare")
+        self._rt = rt
+
+    def _scratch_for(self, tower: int, n: int) -> torch.Tensor:
+        need = _lib.load().fc_train_scratch_bytes(self._rt.handle, tower, n)
+        buf = self._scratch.get(tower)
+        if buf is None or buf.numel() < need:
+            self._scratch[tower] = buf = torch.empty(need, dtype=torch.uint8, device=self.params.device)
+        return buf
+
+    # ------------------------------------------------------------------------------------------------------ forward
+    def forward(self, video: torch.Tensor, text: Mapping[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`encoder(video=..., text=...)` with every activation kept for `backward`: f32 [B, F, 3, R, R] and
+        {"input_ids": int [B, L]} -> (video embeddings [B, E], text embeddings [B, E]), same values as the inference
+        path of the fp32 mode."""
+        lib, rt, dev = _lib.load(), self._rt, self.params.device
+        if rt.fingerprint is None:
+            raise _lib.FitclipHipError("weights changed since the last bind: call StudentTrainer.rebind()")
+        d = self.model.dims
+        b, f = video.shape[:2]
+        frames = video.reshape(b * f, *video.shape[2:]).to(device=dev, dtype=torch.float32).contiguous()
+        ids = text["input_ids"].to(device=dev, dtype=torch.int64).contiguous()
+        zv = torch.empty((b * f, d.embed_dim), dtype=torch.float32, device=dev)
+        zt = torch.empty((ids.shape[0], d.embed_dim), dtype=torch.float32, device=dev)
+        v_chunks, t_chunks = [], []
+        with torch.cuda.device(dev):
+            for s in range(0, b * f, self.max_frames):
+                n = min(self.max_frames, b * f - s)
+                arena = torch.empty(lib.fc_train_arena_bytes(rt.handle, 0, n), dtype=torch.uint8, device=dev)
+                _lib.check(lib.fc_encode_image_train(rt.handle, frames[s:].data_ptr(), n, zv[s:].data_ptr(),
+                                                     arena.data_ptr(), arena.numel(), _lib.current_stream()),
+                           "fc_encode_image_train")
+                v_chunks.append((s, n, arena))
+            for s in range(0, ids.shape[0], self.max_texts):
+                n = min(self.max_texts, ids.shape[0] - s)
+                arena = torch.empty(lib.fc_train_arena_bytes(rt.handle, 1, n), dtype=torch.uint8, device=dev)
+                _lib.check(lib.fc_encode_text_train(rt.handle, ids[s:].data_ptr(), n, zt[s:].data_ptr(),
+                                                    arena.data_ptr(), arena.numel(), _lib.current_stream()),
+                           "fc_encode_text_train")
+                t_chunks.append((s, n, arena))
+        self._state = {"zv": zv, "zt": zt, "ids": ids, "frames": f, "clips": b, "v": v_chunks, "t": t_chunks}
+        return ops.pool_normalize(zv, b, f), ops.l2_normalize(zt)
+
+    # ----------------------------------------------------------------------------------------------------- backward
+    def backward(self, d_video: torch.Tensor, d_text: torch.Tensor, accumulate: bool = False,
+                 reduce_across_ranks: bool = True) -> None:
+        """d(loss)/d(video embeddings) [B, E] and d(loss)/d(text embeddings) [B, E] of the last `forward` -> parameter
+        gradients (`p.grad` of every parameter, i.e. `self.grads`).  With several ranks the gradients are summed over
+        the ranks (text-tower slices first, overlapping the visual backward), which together with the unscaled local
+        slice of the gathered-embedding gradient is what DDP's average of `all_gather(sync_grads=True)` gradients
+        amounts to (`util/tensor_utils.py:48-66`)."""
+        st = self._state
+        if st is None:
+            raise _lib.FitclipHipError("backward() needs a forward() first")
+        lib, rt, dev = _lib.load(), self._rt, self.params.device
+        e = self.model.dims.embed_dim
+        d_video = ops._dev(d_video.contiguous(), "d_video", torch.float32)
+        d_text = ops._dev(d_text.contiguous(), "d_text", torch.float32)
+        dzv, dzt = torch.empty_like(st["zv"]), torch.empty_like(st["zt"])
+        acc = int(accumulate)
+        handles = []
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream()
+            _lib.check(lib.fc_pool_normalize_backward(st["zt"].data_ptr(), d_text.data_ptr(), dzt.data_ptr(),
+                                                      dzt.shape[0], 1, e, stream), "fc_pool_normalize_backward")
+            _lib.check(lib.fc_pool_normalize_backward(st["zv"].data_ptr(), d_video.data_ptr(), dzv.data_ptr(),
+                                                      st["clips"], st["frames"], e, stream),
+                       "fc_pool_normalize_backward")
+            for i, (s, n, arena) in enumerate(st["t"]):
+                scratch = self._scratch_for(1, n)
+                _lib.check(lib.fc_encode_text_backward(rt.handle, st["ids"][s:].data_ptr(), dzt[s:].data_ptr(), n,
+                                                       arena.data_ptr(), arena.numel(), scratch.data_ptr(),
+                                                       scratch.numel(), int(acc or i > 0), stream),
+                           "fc_encode_text_backward")
+            world = D.world()[1]
+            lo, hi = self.visual_span
+            if reduce_across_ranks and world > 1:
+                handles += [D.all_reduce_sum_(self.grads[:lo], async_op=True),
+                            D.all_reduce_sum_(self.grads[hi:], async_op=True)]
+            for i, (s, n, arena) in enumerate(st["v"]):
+                scratch = self._scratch_for(0, n)
+                _lib.check(lib.fc_encode_image_backward(rt.handle, dzv[s:].data_ptr(), n, arena.data_ptr(),
+                                                        arena.numel(), scratch.data_ptr(), scratch.numel(),
+                                                        int(acc or i > 0), stream), "fc_encode_image_backward")
+            if reduce_across_ranks and world > 1:
+                handles.append(D.all_reduce_sum_(self.grads[lo:hi], async_op=True))
+                for h in handles:
+                    if h is not None:
+                        h.wait()
+        self._state = None  # the activation arenas are released
+
+    # ------------------------------------------------------------------------------------------------------- update
+    def step(self) -> None:
+        """One `torch.optim.AdamW` step over all parameters (aligner/cli.py:129; lr 3e-6, config/trainer.yaml:21-23)."""
+        self.step_count += 1
+        with torch.cuda.device(self.params.device):
+            _lib.check(_lib.load().fc_adamw(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                            self.exp_avg_sq.data_ptr(), self.total, self.lr, self.betas[0],
+                                            self.betas[1], self.eps, self.weight_decay, self.step_count,
+                                            _lib.current_stream()), "fc_adamw")
+        self.rebind()
+
+    def rebind(self) -> None:
+        self.model.invalidate_weights()
+        self._bind()
+
+    def zero_grad(self) -> None:
+        self.grads.zero_()
+
+
+def _lengths(datasets: Sequence[str]) -> Tuple[Tuple[str, ...], Tuple[int, ...]]:
+    keys, lengths = zip(*((k, sum(1 for _ in grp)) for k, grp in itertools.groupby(datasets)))
+    return keys, lengths
+
+
+class TeacherStudentTrainer(TeacherStudentModule):
+    """`TeacherStudentLightningModule` as a training loop body (teacher_student.py:44-183): student forward (kept),
+    frozen teacher forward, per-dataset gather + scores + loss (NCE on the labeled part, KD * tau_ts^2 on the unlabeled
+    part, weighted by `dataset_loss_share`), backward into the student, AdamW, temperature clamps."""
+
+    def __init__(self, encoder: ClipVideoTextEncoder, teacher: ClipVideoTextEncoder, labeled_dataset_name: str = "labeled",
+                 labeled_dataset_loss_share: Optional[float] = None,
+                 dataset_names: Iterable[str] = ("labeled", "unlabeled"), init_temperature: float = 0.05,
+                 min_temperature: float = 0.001, fit_temperature: bool = True, lr: float = 3e-6,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 **trainer_kwargs: Any) -> None:
+        super().__init__(encoder, teacher, init_temperature, min_temperature)
+        self.dataset_names = list(dataset_names)
+        assert len(self.dataset_names) == 2, "The current implementation needs exactly 2 datasets."  # :57
+        if labeled_dataset_loss_share is None:                                                       # :61-67
+            self.dataset_loss_share = {name: 1 / len(self.dataset_names) for name in self.dataset_names}
+        else:
+            self.dataset_loss_share = {labeled_dataset_name: labeled_dataset_loss_share}
+            self.dataset_loss_share.update((name, (1 - labeled_dataset_loss_share) / (len(self.dataset_names) - 1))
+                                           for name in self.dataset_names if name != labeled_dataset_name)
+        self.labeled_dataset_name = labeled_dataset_name
+        self.fit_temperature = fit_temperature
+        self.student = StudentTrainer(encoder, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **trainer_kwargs)
+        dev = self.student.params.device
+        # [logit_scale, teacher_student_logit_scale]: value, grad, AdamW moments (the reference hands them to the same
+        # optimiser as the encoder: `self.parameters()`, cli.py:129)
+        self.scales = torch.tensor([self.logit_scale, self.teacher_student_logit_scale] + [0.0] * 2, dtype=torch.float32,
+                                   device=dev)
+        self.scale_grads = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.scale_m = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.scale_v = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._pending: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self.last_losses: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------------------------------------ training_step
+    def training_step(self, batch: Mapping[str, Any]) -> Dict[str, Tuple[Tuple[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]]:
+        """Student (activations kept) and teacher forward over the whole local batch, split per dataset
+        (teacher_student.py:99-140; the `prompts` variant, which scores videos against a fixed prompt list, is not
+        part of this path)."""
+        keys, lengths = _lengths(batch["dataset"])
+        assert len(keys) == len(self.dataset_names), "All datasets should be present in each batch."
+        sv, st = self.student.forward(batch["video_student"], batch["text_student"])
+        with torch.no_grad():
+            tv, tt = self.teacher(video=batch["video_teacher"], text=batch["text_teacher"])
+        out, start = {}, 0
+        for key, n in zip(keys, lengths):
+            sl = slice(start, start + n)
+            out[key] = ((sv[sl], st[sl]), (tv[sl], tt[sl]))
+            start += n
+        self._layout = [(k, n) for k, n in zip(keys, lengths)]
+        self._batch_rows = start
+        return out
+
+    # -------------------------------------------------------------------------------------------- training_step_end
+    def training_step_end(self, output: Mapping[str, Any]) -> float:
+        """sum_d share_d * loss_d (teacher_student.py:142-176), and the gradient of that sum w.r.t. the LOCAL student
+        embeddings (kept for `backward`) and the two temperatures."""
+        lib = _lib.load()
+        rank, world = D.world()
+        dev = self.student.params.device
+        e = self.encoder.model.dims.embed_dim
+        d_video = torch.zeros((self._batch_rows, e), dtype=torch.float32, device=dev)
+        d_text = torch.zeros_like(d_video)
+        self.scale_grads.zero_()
+        ls, ts_ls = float(self.scales[0]), float(self.scales[1])
+        scale, ts_scale = math.exp(ls), math.exp(ts_ls)
+        total, start = 0.0, 0
+        self.last_losses = {}
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream()
+            for name, n_local in self._layout:
+                (v, t), (tv, tt) = output[name]
+                counts = [n_local] * world
+                v_all, t_all, tv_all, tt_all = D.all_gather_many((v.contiguous(), t.contiguous(), tv.contiguous(),
+                                                                  tt.contiguous()), counts)
+                n = v_all.shape[0]
+                share = self.dataset_loss_share[name]
+                scores = ops.similarity(v_all, t_all, alpha=scale).contiguous()
+                dscores = torch.empty_like(scores)
+                ws = torch.empty(6 * n, dtype=torch.float32, device=dev)
+                if name == self.labeled_dataset_name:
+                    loss = ops.nce_loss(scores)
+                    _lib.check(lib.fc_nce_loss_backward(scores.data_ptr(), n, share, dscores.data_ptr(), ws.data_ptr(),
+                                                        stream), "fc_nce_loss_backward")
+                else:
+                    teacher_scores = ops.similarity(tv_all, tt_all, alpha=ts_scale).contiguous()
+                    kd = ops.teacher_student_nce_loss(scores, teacher_scores)
+                    loss = kd * ts_scale ** 2
+                    _lib.check(lib.fc_kd_loss_backward(scores.data_ptr(), teacher_scores.data_ptr(), n,
+                                                       share * ts_scale ** 2, dscores.data_ptr(), ws.data_ptr(), stream),
+                               "fc_kd_loss_backward")
+                    if self.fit_temperature:
+                        # d/d(ts_ls) [kd(S, e^ts_ls X) e^(2 ts_ls)] = e^(2 ts_ls) (sum dkd/dT * T + 2 kd)
+                        tmp = torch.empty(1, dtype=torch.float32, device=dev)
+                        _lib.check(lib.fc_kd_teacher_scale_grad(scores.data_ptr(), teacher_scores.data_ptr(), n,
+                                                                tmp.data_ptr(), ws.data_ptr(), stream),
+                                   "fc_kd_teacher_scale_grad")
+                        self.scale_grads[1] += share * ts_scale ** 2 * (tmp[0] + 2.0 * kd)
+                if self.fit_temperature:  # scores = e^ls X  =>  d loss / d ls = sum(dscores * scores)
+                    _lib.check(lib.fc_dot(dscores.data_ptr(), scores.data_ptr(), n * n, 1.0, 1.0,
+                                          self.scale_grads.data_ptr(), stream), "fc_dot")
+                # scores = scale V T^T  =>  dV = scale dS T,  dT = scale dS^T V   (full gathered matrices; local rows kept)
+                dscores_t = torch.empty_like(dscores)
+                _lib.check(lib.fc_transpose(dscores.data_ptr(), dscores_t.data_ptr(), n, n, stream), "fc_transpose")
+                dv_all = ops.gemm_tn(dscores_t, t_all, alpha=scale)
+                dt_all = ops.gemm_tn(dscores, v_all, alpha=scale)
+                lo = rank * n_local
+                d_video[start:start + n_local] = dv_all[lo:lo + n_local]
+                d_text[start:start + n_local] = dt_all[lo:lo + n_local]
+                self.last_losses[name] = float(loss)
+                total += share * self.last_losses[name]
+                start += n_local
+        self._pending = (d_video, d_text)
+        return total
+
+    def backward(self) -> None:
+        if self._pending is None:
+            raise _lib.FitclipHipError("backward() needs training_step_end() first")
+        self.student.backward(*self._pending)
+        self._pending = None
+
+    # ----------------------------------------------------------------------------------------------- optimizer_step
+    def optimizer_step(self) -> None:
+        """AdamW over the encoder and (with `fit_temperature`) the two temperatures, then the clamps of
+        video_text_module.py:94-97 and teacher_student.py:179-183."""
+        self.student.step()
+        if self.fit_temperature:
+            s = self.student
+            with torch.cuda.device(self.scales.device):
+                _lib.check(_lib.load().fc_adamw(self.scales.data_ptr(), self.scale_grads.data_ptr(),
+                                                self.scale_m.data_ptr(), self.scale_v.data_ptr(), 2, s.lr, s.betas[0],
+                                                s.betas[1], s.eps, s.weight_decay, s.step_count, _lib.current_stream()),
+                           "fc_adamw")
+            self.scales[:2].clamp_(max=self.max_logit_scale)
+        self.logit_scale, self.teacher_student_logit_scale = (float(x) for x in self.scales[:2].tolist())
+
+    def fit_step(self, batch: Mapping[str, Any]) -> float:
+        loss = self.training_step_end(self.training_step(batch))
+        self.backward()
+        self.optimizer_step()
+        return loss

@@ -156,6 +156,64 @@ FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
 
+/* ---- training: the KD fine-tuning step of the student -------------------------------------------
+ * Replaces autograd + torch.optim.AdamW for `TeacherStudentLightningModule.training_step / training_step_end /
+ * optimizer_step` (aligner/teacher_student.py:99-183, aligner/video_text_module.py:94-97, aligner/cli.py:129).
+ * Only precision fp32 handles train (the reference trains in float32).  Call order per optimiser step:
+ *   fc_train_prepare (transposed weight copies for the dgrad GEMMs; after fc_pack_weights, again after every update)
+ *   fc_encode_image_train / fc_encode_text_train   forward of a tower, every activation kept in `arena`
+ *   ... loss and its gradient w.r.t. the tower outputs (fc_similarity, fc_*_loss_backward, fc_gemm_tn,
+ *       fc_pool_normalize_backward) ...
+ *   fc_encode_image_backward / fc_encode_text_backward   parameter gradients into the buffers given by fc_set_grad
+ *   fc_adamw over the (flat) parameter / gradient / moment buffers.
+ * `arena` (>= fc_train_arena_bytes) and `scratch` (>= fc_train_scratch_bytes) are caller-owned, 256-byte aligned. */
+FC_API int fc_set_grad(fc_handle* h, const char* name, float* dev_f32);        /* borrowed, same shape as the weight */
+FC_API size_t fc_train_weights_bytes(const fc_handle* h);
+FC_API int fc_train_prepare(fc_handle* h, void* dev_arena, size_t arena_bytes, fc_stream stream);
+FC_API size_t fc_train_arena_bytes(const fc_handle* h, int32_t tower, int32_t n);
+FC_API size_t fc_train_scratch_bytes(const fc_handle* h, int32_t tower, int32_t n);
+/* out = CLIP.encode_image(frames) / CLIP.encode_text(ids) (NOT normalised), bit-identical to the inference entry points */
+FC_API int fc_encode_image_train(fc_handle* h, const float* frames, int32_t n, float* out, void* arena, size_t arena_bytes,
+                          fc_stream stream);
+FC_API int fc_encode_text_train(fc_handle* h, const int64_t* ids, int32_t n, float* out, void* arena, size_t arena_bytes,
+                         fc_stream stream);
+/* d_out dev f32 [n, embed_dim] = dLoss / d(out of the *_train call that filled `arena`).  accumulate = 0: gradients
+ * are overwritten; 1: added (several micro-batches per optimiser step). */
+FC_API int fc_encode_image_backward(fc_handle* h, const float* d_out, int32_t n, void* arena, size_t arena_bytes,
+                             void* scratch, size_t scratch_bytes, int32_t accumulate, fc_stream stream);
+FC_API int fc_encode_text_backward(fc_handle* h, const int64_t* ids, const float* d_out, int32_t n, void* arena,
+                            size_t arena_bytes, void* scratch, size_t scratch_bytes, int32_t accumulate,
+                            fc_stream stream);
+/* backward of fc_pool_normalize (frames = 1: of fc_l2_normalize): z [n_clips * frames, dim] the un-normalised tower
+ * output, d_out [n_clips, dim] -> d_z [n_clips * frames, dim] */
+FC_API int fc_pool_normalize_backward(const float* z, const float* d_out, float* d_z, int32_t n_clips, int32_t frames,
+                               int32_t dim, fc_stream stream);
+/* d_scores = coef * dLoss/dscores of fc_nce_loss / fc_kd_loss (aligner/loss.py:13-39, "mean" / "batchmean");
+ * ws: 2 n (NCE) or 4 n (KD) floats */
+FC_API int fc_nce_loss_backward(const float* scores, int32_t n, float coef, float* d_scores, float* ws, fc_stream stream);
+FC_API int fc_kd_loss_backward(const float* scores, const float* teacher_scores, int32_t n, float coef, float* d_scores,
+                        float* ws, fc_stream stream);
+/* out[0] = sum_ij dKD/dteacher_scores[i,j] * teacher_scores[i,j]: what the teacher-student temperature (a factor of
+ * every teacher score, teacher_student.py:68-69,157) receives through the teacher scores.  ws: 6 n floats */
+FC_API int fc_kd_teacher_scale_grad(const float* scores, const float* teacher_scores, int32_t n, float* out, float* ws,
+                             fc_stream stream);
+/* C[N1, N2] = beta C + alpha sum_m A[m, N1] B[m, N2], exact fp32 (weight gradients dW = dY^T X; and dV = dS T,
+ * dT = dS^T V of the similarity, video_text_module.py:63).  scratch >= fc_gemm_tn_scratch_bytes, 256-byte aligned. */
+FC_API size_t fc_gemm_tn_scratch_bytes(int32_t M, int32_t N1, int32_t N2);
+FC_API int fc_gemm_tn(const float* A, const float* B, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
+               float alpha, float beta, float* C, int32_t ldc, void* scratch, size_t scratch_bytes, fc_stream stream);
+FC_API int fc_attention_backward(int32_t precision, const void* qkv, const void* out, const void* d_out, void* d_qkv,
+                          int32_t n_seq, int32_t S, int32_t heads, int32_t causal, fc_stream stream);
+FC_API size_t fc_layernorm_backward_scratch_bytes(int32_t D);
+FC_API int fc_layernorm_backward(const float* x, const float* d_y, const float* gamma, float* d_x, int32_t accumulate,
+                          int32_t rows, int32_t D, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes,
+                          fc_stream stream);
+FC_API int fc_dot(const float* a, const float* b, size_t n, float alpha, float beta, float* out, fc_stream stream);
+FC_API int fc_transpose(const float* in, float* out, int32_t rows, int32_t cols, fc_stream stream);
+/* torch.optim.AdamW step `step` (counted from 1) over n floats (aligner/cli.py:129, config/trainer.yaml:21-23) */
+FC_API int fc_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+             double beta2, double eps, double weight_decay, int32_t step, fc_stream stream);
+
 /* ---- kernel timing (bench.py roofline leg): hipEvent pairs around the GEMM, attention and add+LayerNorm launches
  * of the transformer blocks, on the caller's stream ----------------------------------------------------------------- */
 typedef struct {

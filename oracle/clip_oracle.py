@@ -18,6 +18,9 @@ this path.  Each function cites the reference lines it follows (paths relative t
   * score matrix, Recall@k, rank, median rank ........................... aligner/text_video_retrieval.py:67-83,
                                                                           aligner/metrics.py:16-36
   * all_gather flattening of [world, B, ...] ............................ util/tensor_utils.py:48-66
+  * KD training loss (per-dataset NCE / KD * tau^2, loss shares) ........ aligner/teacher_student.py:142-176
+    (its gradients are torch autograd through this restatement; pinned against autograd through the reference's
+    own slip / loss classes by tests/golden/make_goldens.py::golden_training)
 
 Pinning (see tests/golden/make_goldens.py and DESIGN.md "Oracle"): checked in the build container against the
 reference's own `aligner.wise` (direct import), `aligner.loss` and `aligner.encoder.slip` transformer / text tower
@@ -166,6 +169,29 @@ def step_scores(encoded_video: torch.Tensor, encoded_text: torch.Tensor, init_te
     """video_text_module.py:32,62-63: logit_scale = -log(T); scores = exp(logit_scale) * V @ T^T."""
     logit_scale = torch.tensor([-math.log(init_temperature)]).exp()
     return logit_scale * encoded_video @ encoded_text.T
+
+
+def teacher_student_training_loss(student_out: Mapping[str, Tuple[torch.Tensor, torch.Tensor]],
+                                  teacher_out: Mapping[str, Tuple[torch.Tensor, torch.Tensor]],
+                                  logit_scale: torch.Tensor, teacher_student_logit_scale: torch.Tensor,
+                                  dataset_loss_share: Mapping[str, float], labeled_dataset_name: str = "labeled"
+                                  ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """teacher_student.py:142-176 (`_dataset_step_end` + `training_step_end`) on already gathered embeddings:
+    per dataset `scores = exp(logit_scale) * V @ T^T`; NCE on the labeled dataset, KD("batchmean") * exp(ts_scale)^2 on
+    the other; total = sum_d share_d * loss_d.  Differentiable (plain torch): autograd through it and the towers above is
+    the oracle of the training step."""
+    losses = {}
+    for name, (video, text) in student_out.items():
+        scores = logit_scale.exp() * video @ text.T
+        if name == labeled_dataset_name:
+            losses[name] = nce_loss(scores)
+        else:
+            t_video, t_text = teacher_out[name]
+            ts = teacher_student_logit_scale.exp()
+            teacher_scores = ts * t_video @ t_text.T
+            losses[name] = teacher_student_nce_loss(scores, teacher_scores) * ts ** 2
+    total = sum(losses[name] * dataset_loss_share[name] for name in losses)
+    return total, losses
 
 
 # ---------------------------------------------------------------------------------------------------------- metrics

@@ -273,6 +273,88 @@ def golden_wise_encoder(report) -> None:
     report["wise_encoder_tiny"] = "oracle outputs stored"
 
 
+def golden_training(ref_loss, ref_slip, report) -> None:
+    """Pins the oracle's BACKWARD: one KD training step (teacher_student.py:142-176: NCE on the labeled half, KD * tau^2
+    on the unlabeled half, shares 0.5 / 0.5) on the tiny dims, differentiated by autograd (i) through the REFERENCE's own
+    `slip.CLIP.encode_text`, `slip.Transformer` / `LayerNorm` blocks and `aligner.loss` classes and (ii) through the
+    oracle; the parameter gradients must agree, and a digest of them is stored for the GPU test."""
+    d = synth.TINY
+    teacher_np = synth.make_state_dict(d, seed=42)
+    student_np = synth.perturbed_state_dict(teacher_np, d, seed=5, rel=0.3)
+    n, f, n_lab, temp = 8, 2, 4, 0.05
+    video = torch.from_numpy(synth.make_video(n, f, d, seed=9))
+    ids = torch.from_numpy(synth.make_text(n, d, seed=9))
+    images = video.reshape(-1, *video.shape[2:])
+    share = {"labeled": 0.5, "unlabeled": 0.5}
+    ls = torch.tensor([-np.log(temp)], dtype=torch.float32)
+
+    def pool(img_feats):
+        e = img_feats / img_feats.norm(dim=-1, keepdim=True)
+        return e.view(n, f, -1).mean(1)
+
+    with torch.no_grad():
+        t_sd = O.to_torch(teacher_np)
+        tv, tt = O.forward(t_sd, video, {"input_ids": ids})
+
+    def total_loss(ev, et, nce, kd):
+        s_lab = ls.exp() * ev[:n_lab] @ et[:n_lab].T
+        s_unl = ls.exp() * ev[n_lab:] @ et[n_lab:].T
+        t_unl = ls.exp() * tv[n_lab:] @ tt[n_lab:].T
+        return share["labeled"] * nce(s_lab) + share["unlabeled"] * kd(s_unl, t_unl) * ls.exp() ** 2
+
+    # (i) the reference's classes
+    sd_ref = {k: v.clone() for k, v in O.to_torch(student_np).items()}
+    txt = _slip_text_model(ref_slip, d, sd_ref).train()
+    tr = ref_slip.Transformer(d.vision_width, d.vision_layers, d.vision_heads)
+    pre = "visual.transformer."
+    tr.load_state_dict({k[len(pre):]: v for k, v in sd_ref.items() if k.startswith(pre)})
+    ln_pre, ln_post = ref_slip.LayerNorm(d.vision_width), ref_slip.LayerNorm(d.vision_width)
+    ln_pre.load_state_dict({"weight": sd_ref["visual.ln_pre.weight"], "bias": sd_ref["visual.ln_pre.bias"]})
+    ln_post.load_state_dict({"weight": sd_ref["visual.ln_post.weight"], "bias": sd_ref["visual.ln_post.bias"]})
+    leaves = {k: sd_ref[k].clone().requires_grad_(True) for k in
+              ("visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding", "visual.proj")}
+    x = torch.nn.functional.conv2d(images, leaves["visual.conv1.weight"], stride=d.vision_patch_size)
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    x = torch.cat([leaves["visual.class_embedding"].expand(x.shape[0], 1, -1), x], dim=1)
+    x = ln_pre(x + leaves["visual.positional_embedding"])
+    x = tr(x.permute(1, 0, 2)).permute(1, 0, 2)
+    ev_ref = pool(ln_post(x[:, 0, :]) @ leaves["visual.proj"])
+    et_ref = txt.encode_text(ids)
+    et_ref = et_ref / et_ref.norm(dim=-1, keepdim=True)
+    loss_ref = total_loss(ev_ref, et_ref, ref_loss.NCELoss(), ref_loss.TeacherStudentNCELoss(reduction="batchmean"))
+    loss_ref.backward()
+    grads_ref = {k: v.grad for k, v in leaves.items()}
+    grads_ref.update({pre + k: p.grad for k, p in tr.named_parameters()})
+    grads_ref.update({f"visual.ln_pre.{k}": p.grad for k, p in ln_pre.named_parameters()})
+    grads_ref.update({f"visual.ln_post.{k}": p.grad for k, p in ln_post.named_parameters()})
+    grads_ref.update({k: p.grad for k, p in txt.named_parameters() if p.grad is not None})
+
+    # (ii) the oracle
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch(student_np).items()}
+    ev, et = O.forward(sd, video, {"input_ids": ids})
+    loss, parts = O.teacher_student_training_loss(
+        {"labeled": (ev[:n_lab], et[:n_lab]), "unlabeled": (ev[n_lab:], et[n_lab:])},
+        {"labeled": (tv[:n_lab], tt[:n_lab]), "unlabeled": (tv[n_lab:], tt[n_lab:])}, ls, ls.clone(), share)
+    loss.backward()
+    assert set(grads_ref) == set(sd), set(sd) ^ set(grads_ref)
+    worst = 0.0
+    for k, p in sd.items():
+        ref = grads_ref[k]
+        rel = float((p.grad - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        worst = max(worst, rel)
+        assert rel < 2e-4, (k, rel)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    out = {"n": n, "f": f, "n_labeled": n_lab, "temperature": temp, "video_seed": 9, "student_seed": 5, "rel": 0.3,
+           "loss": np.float64(loss_ref.item()), "loss_labeled": np.float64(parts["labeled"].item()),
+           "loss_unlabeled": np.float64(parts["unlabeled"].item())}
+    for k, g in grads_ref.items():
+        out[f"norm/{k}"] = np.float64(g.double().norm().item())
+        if g.numel() <= 4096:
+            out[f"grad/{k}"] = g.detach().numpy()
+    np.savez(HERE / "training_ref_tiny.npz", **out)
+    report["training_gradients_oracle_vs_reference_slip+loss_max_rel"] = worst
+
+
 def _learn_toy_merges(words, n_merges):
     """A small BPE trainer (ours) so that the merges file is synthetic data, not a copy of the published vocabulary."""
     from collections import Counter
@@ -345,6 +427,7 @@ def main() -> None:
     golden_evaluate(report)
     golden_wise_encoder(report)
     golden_bpe(ref_slip, report)
+    golden_training(ref_loss, ref_slip, report)
     (HERE / "PINNING.json").write_text(json.dumps(report, indent=2) + "\n")
     print(json.dumps(report, indent=2))
 
