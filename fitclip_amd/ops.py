@@ -169,6 +169,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out: Optional[
         raise ValueError(f"gemm_tn needs [M, N1] and [M, N2], got {tuple(a.shape)} and {tuple(b.shape)}")
     M, N1 = a.shape
     N2 = b.shape[1]
+    if N1 % 4 or N2 % 4:  # the kernel moves 16-byte chunks: zero-pad the column counts, drop the padding afterwards
+        if out is not None:
+            raise ValueError("column counts that are not multiples of 4 need out=None")
+        pad = lambda t, n: torch.nn.functional.pad(t, (0, -n % 4)) if n % 4 else t  # noqa: E731
+        return gemm_tn(pad(a, N1).contiguous(), pad(b, N2).contiguous(), alpha)[:N1, :N2].contiguous()
     if out is None:
         if beta != 0.0:
             raise ValueError("beta needs an `out` to accumulate into")

@@ -91,7 +91,8 @@ def test_layernorm_backward_matches_autograd(rows, D):
     dx = torch.ones(rows, D, device=DEV)
     dgam, dbet = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
     scratch = torch.empty(lib.fc_layernorm_backward_scratch_bytes(D), dtype=torch.uint8, device=DEV)
-    _lib.check(lib.fc_layernorm_backward(x.to(DEV).data_ptr(), dy.to(DEV).data_ptr(), gamma.to(DEV).data_ptr(), dx.data_ptr(), 1,
+    x_d, dy_d, gamma_d = x.to(DEV), dy.to(DEV), gamma.to(DEV)  # named: a temporary's memory is reused by the next one
+    _lib.check(lib.fc_layernorm_backward(x_d.data_ptr(), dy_d.data_ptr(), gamma_d.data_ptr(), dx.data_ptr(), 1,
                                          rows, D, dgam.data_ptr(), dbet.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream()))
     assert _rel(dx - 1.0, xd.grad) < 2e-5     # accumulate = 1: added to what was there
     assert _rel(dgam, gd.grad) < 2e-5 and _rel(dbet, bd.grad) < 2e-5
@@ -123,7 +124,8 @@ def test_pool_normalize_backward_matches_autograd():
     x = z.double().requires_grad_(True)
     ((x / x.norm(dim=-1, keepdim=True)).view(6, 4, 128).mean(1)).backward(dout.double())
     dz = torch.empty(24, 128, device=DEV)
-    _lib.check(_lib.load().fc_pool_normalize_backward(z.to(DEV).data_ptr(), dout.to(DEV).data_ptr(), dz.data_ptr(), 6, 4, 128, _stream()))
+    z_d, dout_d = z.to(DEV), dout.to(DEV)
+    _lib.check(_lib.load().fc_pool_normalize_backward(z_d.data_ptr(), dout_d.data_ptr(), dz.data_ptr(), 6, 4, 128, _stream()))
     assert _rel(dz, x.grad) < 1e-5
 
 
@@ -246,6 +248,10 @@ def test_optimizer_steps_match_torch_adamw(tiny_state_dict):
     opt = torch.optim.AdamW([*ref_sd.values(), ref_ls, ref_ts], lr=lr)
     with torch.no_grad():
         t_sd = O.to_torch(tiny_state_dict)
+    # AdamW's first steps move every weight by ~lr * sign(gradient) whatever the gradient's size, so where the true
+    # gradient is ZERO (the key third of every in_proj_bias: softmax ignores a shift common to all keys) the update is
+    # the sign of rounding noise.  Elements are compared only while their gradient has been well above noise level.
+    solid = {k: torch.ones_like(v.data, dtype=torch.bool) for k, v in ref_sd.items()}
     for step in range(2):
         video = torch.from_numpy(synth.make_video(n, f, d, seed=20 + step))
         ids = torch.from_numpy(synth.make_text(n, d, seed=20 + step))
@@ -257,6 +263,8 @@ def test_optimizer_steps_match_torch_adamw(tiny_state_dict):
             {"labeled": (tv[:n_lab], tt[:n_lab]), "unlabeled": (tv[n_lab:], tt[n_lab:])}, ref_ls, ref_ts, share)
         opt.zero_grad()
         loss.backward()
+        for k, v in ref_sd.items():
+            solid[k] &= v.grad.abs() > 2e-4 * v.grad.abs().max()
         opt.step()
         with torch.no_grad():  # video_text_module.py:94-97, teacher_student.py:179-183
             ref_ls.clamp_(max=-math.log(0.001))
@@ -267,7 +275,9 @@ def test_optimizer_steps_match_torch_adamw(tiny_state_dict):
             # AdamW's first steps move every weight by ~lr regardless of the gradient's size: compare the UPDATE
             upd_ref = ref_sd[k].detach() - torch.from_numpy(student_np[k])
             upd = p.detach().cpu() - torch.from_numpy(student_np[k])
-            assert (upd - upd_ref).abs().max() < 0.02 * lr * (step + 1) + 1e-7, (step, k, float((upd - upd_ref).abs().max()))
+            assert solid[k].any(), k
+            assert (upd - upd_ref)[solid[k]].abs().max() < 0.02 * lr * (step + 1) + 1e-7, (step, k)
+            assert upd.abs().max() <= 1.05 * lr * (step + 1) + 1e-3 * lr, (step, k)
         assert abs(module.logit_scale - float(ref_ls)) < 0.02 * lr * (step + 1)
         assert abs(module.teacher_student_logit_scale - float(ref_ts)) < 0.02 * lr * (step + 1)
     for k, p in module.teacher.model.named_parameters():
@@ -276,7 +286,10 @@ def test_optimizer_steps_match_torch_adamw(tiny_state_dict):
     video = torch.from_numpy(synth.make_video(3, f, d, seed=1))
     with torch.no_grad():
         want = O.encode_video({k: v.detach() for k, v in ref_sd.items()}, video)
-    assert (module.encoder.encode_video(video.to(DEV)).cpu() - want).abs().max() < 1e-4
+    assert (module.encoder.encode_video(video.to(DEV)).cpu() - want).abs().max() < 2e-2  # weights differ by <= 2 lr where noise decided
+    fresh = ClipVideoTextEncoder(build_clip({k: p.detach().cpu().numpy() for k, p in module.encoder.model.named_parameters()},
+                                            precision="fp32", device=DEV))
+    assert torch.equal(fresh.encode_video(video.to(DEV)), module.encoder.encode_video(video.to(DEV)))  # repacked after the step
 
 
 def test_training_step_at_one_ranks_share_of_config5(vitb16_state_dict):
