@@ -34,7 +34,7 @@ CONFIG_DIR = Path(__file__).resolve().parent / "config"
 DEFAULTS: Dict[str, Any] = {
     "command": "evaluate", "encoder": "clip_vit_b_16", "data": "synthetic", "seed": 42, "n_clips": 64,
     "num_frames": 4, "eval_batch_size": 32, "init_temperature": 0.015, "precision": None, "weight_for_2": None,
-    "gpus": 1, "backend": "nccl",
+    "gpus": 1, "backend": "nccl", "bpe_path": None,
 }
 
 
@@ -76,6 +76,8 @@ def load_encoder_config(name: str, cfg: Mapping[str, Any], device: Any = None) -
                     n["device"] = str(device)  # weights go straight to the ROCm device (WiSE blends there)
             if "num_frames" in n:
                 n["num_frames"] = cfg["num_frames"]
+            if "bpe_path" in n and cfg.get("bpe_path"):
+                n["bpe_path"] = cfg["bpe_path"]
             for v in n.values():
                 patch(v)
 

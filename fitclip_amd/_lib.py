@@ -86,6 +86,14 @@ SIGNATURES = {
     "fc_dot": (_i32, [_vp, _vp, _sz, _f32, _f32, _vp, _vp]),
     "fc_transpose": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fc_adamw": (_i32, [_vp, _vp, _vp, _vp, _sz, _f64, _f64, _f64, _f64, _f64, _i32, _vp]),
+    "fc_bpe_create": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
+    "fc_bpe_destroy": (None, [_vp]),
+    "fc_bpe_vocab_size": (_i32, [_vp]),
+    "fc_bpe_sot": (_i32, [_vp]),
+    "fc_bpe_eot": (_i32, [_vp]),
+    "fc_bpe_encode": (_i32, [_vp, C.c_char_p, C.POINTER(_i64), _i32]),
+    "fc_bpe_tokenize": (_i32, [_vp, C.POINTER(C.c_char_p), _i32, _i32, _vp]),
+    "fc_bpe_decode": (_i32, [_vp, C.POINTER(_i64), _i32, C.c_char_p, _i32]),
     "fc_profile_enable": (_i32, [_vp, _i32]),
     "fc_profile_select": (_i32, [_vp, C.c_uint32, C.c_uint32]),
     "fc_profile_reset": (_i32, [_vp]),

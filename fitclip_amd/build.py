@@ -14,8 +14,9 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 REPO = CSRC.parent.parent
 LIB = CSRC / "libfitclip_hip.so"
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
-           "train.hip"]
-HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "handle.h", REPO / "include" / "fitclip_hip.h"]
+           "train.hip", "bpe.cpp"]
+HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "handle.h", CSRC / "unicode_ranges.inc",
+           REPO / "include" / "fitclip_hip.h"]
 ARCH = "gfx950"
 
 
@@ -94,7 +95,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
              "-fvisibility=hidden", "-DFITCLIP_BUILD"]
 
     def compile_one(src: str) -> Path:
-        obj = objdir / (src.replace(".hip", ".o"))
+        obj = objdir / (src.replace(".hip", ".o").replace(".cpp", ".o"))
         if force or _stale(obj, [CSRC / src, *HEADERS]):
             cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
             if save_temps or src in ASYNC_LOAD_AUDIT:
@@ -113,7 +114,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-lz"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

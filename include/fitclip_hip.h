@@ -214,6 +214,25 @@ FC_API int fc_transpose(const float* in, float* out, int32_t rows, int32_t cols,
 FC_API int fc_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
              double beta2, double eps, double weight_decay, int32_t step, fc_stream stream);
 
+/* ---- CLIP BPE tokenizer (host C++) -----------------------------------------------------------------
+ * `clip.tokenize(texts, truncate=True)` (clip_video_text_encoder.py:64-65) = `SimpleTokenizer` of
+ * aligner/encoder/slip.py:75-164 over a LOCAL gzip merges file (`bpe_simple_vocab_16e6.txt.gz` layout: a header line,
+ * then one "a b" merge per line, the first 48 894 kept).  Texts are UTF-8, already cleaned and lower-cased by the caller
+ * (html.unescape x2, white-space collapse, str.lower: slip.py:60-72,138).  Not thread-safe per handle (merge cache). */
+typedef struct fc_bpe fc_bpe;
+FC_API int fc_bpe_create(const char* merges_gz_path, int32_t context_length, fc_bpe** out);
+FC_API void fc_bpe_destroy(fc_bpe* t);
+FC_API int32_t fc_bpe_vocab_size(const fc_bpe* t);          /* len(encoder): 49 408 for the published file */
+FC_API int32_t fc_bpe_sot(const fc_bpe* t);                 /* id of <|startoftext|> (49 406) */
+FC_API int32_t fc_bpe_eot(const fc_bpe* t);                 /* id of <|endoftext|>   (49 407) */
+/* ids of one text WITHOUT framing (SimpleTokenizer.encode); returns the count (may exceed `capacity`: call again) */
+FC_API int32_t fc_bpe_encode(fc_bpe* t, const char* text_utf8, int64_t* out_ids, int32_t capacity);
+/* out_ids host int64 [n, context_length]: SOT, ids, EOT, zero padding; too long: cut with EOT in the last slot when
+ * `truncate`, FC_EINVAL otherwise */
+FC_API int fc_bpe_tokenize(fc_bpe* t, const char* const* texts_utf8, int32_t n, int32_t truncate, int64_t* out_ids);
+/* UTF-8 bytes of the decoded text ("</w>" -> " "); returns the byte count (NUL-terminated if it fits `capacity`) */
+FC_API int32_t fc_bpe_decode(const fc_bpe* t, const int64_t* ids, int32_t n, char* out, int32_t capacity);
+
 /* ---- kernel timing (bench.py roofline leg): hipEvent pairs around the GEMM, attention and add+LayerNorm launches
  * of the transformer blocks, on the caller's stream ----------------------------------------------------------------- */
 typedef struct {

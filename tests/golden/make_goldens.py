@@ -358,7 +358,7 @@ def golden_training(ref_loss, ref_slip, report) -> None:
 def _learn_toy_merges(words, n_merges):
     """A small BPE trainer (ours) so that the merges file is synthetic data, not a copy of the published vocabulary."""
     from collections import Counter
-    from fitclip_amd.bpe import byte_alphabet
+    from oracle.bpe_oracle import byte_alphabet
     alpha = byte_alphabet()
     vocab = Counter()
     for w in words:
@@ -390,9 +390,11 @@ def _learn_toy_merges(words, n_merges):
 
 
 def golden_bpe(ref_slip, report) -> None:
-    """Pins fitclip_amd.bpe against the reference's own `SimpleTokenizer` class on a synthetic merges file."""
+    """Pins the tokenizer (C++ core `fc_bpe_*` behind fitclip_amd.bpe, and the Python restatement under oracle/) against
+    the reference's own `SimpleTokenizer` class on a small synthetic merges file."""
     import gzip
-    from fitclip_amd.bpe import ClipBpeTokenizer, byte_alphabet
+    from fitclip_amd.bpe import ClipBpeTokenizer
+    from oracle.bpe_oracle import ClipBpeTokenizer as OracleBpe, byte_alphabet
     assert dict(enumerate(byte_alphabet())) == ref_slip.bytes_to_unicode()
     corpus = ("a video of a person playing guitar in the kitchen while the dog is running on the beach people dancing "
               "cooking food slowly quickly cats dogs birds swimming pool water blue sky playing played player "
@@ -407,13 +409,45 @@ def golden_bpe(ref_slip, report) -> None:
              "cooking   food\tslowly 123 times", "na\u00efve caf\u00e9 \u2014 \u00fcn\u00efc\u00f6d\u00e9 \u2603", "x" * 40,
              "<|startoftext|> hi <|endoftext|>", "", "I'm they've it'll"]
     expected = [ref_tok.encode(t) for t in texts]
+    oracle_tok = OracleBpe(str(path), context_length=16)
     for t, e in zip(texts, expected):
-        assert mine.encode(t) == e, t
-        assert mine.decode(e) == ref_tok.decode(e), t
+        assert mine.encode(t) == e and oracle_tok.encode(t) == e, t
+        assert mine.decode(e) == ref_tok.decode(e) == oracle_tok.decode(e), t
     (HERE / "bpe_toy.json").write_text(json.dumps({"texts": texts, "ids": expected,
                                                    "decoded": [ref_tok.decode(e) for e in expected],
                                                    "vocab_size": len(ref_tok.encoder)}, indent=1) + "\n")
     report["bpe_vs_reference_slip.SimpleTokenizer"] = f"identical ids on {len(texts)} texts (toy merges, vocab {len(ref_tok.encoder)})"
+
+
+def golden_bpe_full(ref_slip, report) -> None:
+    """The same pin at FULL vocabulary size: a synthetic 48 894-merge file (tests/golden/synth_merges.py; the published
+    vocabulary is not available offline) -> the reference's SimpleTokenizer must report SOT 49406 / EOT 49407 and its
+    `encode` ids for a set of texts become the fixture the C++ tokenizer is tested against on any box."""
+    sys.path.insert(0, str(HERE))
+    from synth_merges import write_synthetic_merges
+    from fitclip_amd.bpe import ClipBpeTokenizer
+    path = os.path.join(tempfile.mkdtemp(prefix="fitclip_bpe_"), "synthetic_full_merges.txt.gz")
+    words = write_synthetic_merges(path, seed=0)
+    ref_tok = ref_slip.SimpleTokenizer(bpe_path=path)
+    assert ref_tok.encoder["<|startoftext|>"] == 49406 and ref_tok.encoder["<|endoftext|>"] == 49407
+    rng = __import__("random").Random(3)
+    texts = [" ".join(rng.choice(words) for _ in range(rng.randrange(1, 12))) for _ in range(40)]
+    texts += ["A video of a person playing guitar!", "the dog's running... on the BEACH &amp;amp; pool &lt;3",
+              "It's 12:30pm, they're HERE; we'll see!!  (really?)", "na\u00efve caf\u00e9 \u2014 \u00fcn\u00efc\u00f6d\u00e9 \u2603 \U0001F600",
+              "<|startoftext|> hi <|endoftext|> there", "", "   ", "x" * 40, "tabs\tand\nnewlines\x0b\x0c\x1c mixed \xa0 nbsp",
+              "\u017fign 'S 'T don'T I'LL \u212a9 \u0660\u0661 \u00b2 \u2167", " ".join(words[100:260])]
+    expected = [ref_tok.encode(t) for t in texts]
+    framed = ref_tok(texts, context_length=77)
+    mine = ClipBpeTokenizer(path, context_length=77)
+    for t, e in zip(texts, expected):
+        assert mine.encode(t) == e, t
+        assert mine.decode(e) == ref_tok.decode(e), t
+    (HERE / "bpe_full.json").write_text(json.dumps({
+        "merges_seed": 0, "n_merges": 49152 - 256 - 2, "texts": texts, "ids": expected,
+        "decoded": [ref_tok.decode(e) for e in expected], "len_encoder": len(ref_tok.encoder),
+        "slip_call_context77": framed.tolist(), "sot": 49406, "eot": 49407}, indent=0) + "\n")
+    report["bpe_full_vocab_vs_reference_slip.SimpleTokenizer"] = (
+        f"identical ids on {len(texts)} texts (synthetic 48894-merge file, SOT 49406, EOT 49407, len(encoder) {len(ref_tok.encoder)})")
 
 
 def main() -> None:
@@ -427,6 +461,7 @@ def main() -> None:
     golden_evaluate(report)
     golden_wise_encoder(report)
     golden_bpe(ref_slip, report)
+    golden_bpe_full(ref_slip, report)
     golden_training(ref_loss, ref_slip, report)
     (HERE / "PINNING.json").write_text(json.dumps(report, indent=2) + "\n")
     print(json.dumps(report, indent=2))

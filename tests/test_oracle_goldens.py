@@ -123,21 +123,70 @@ def test_synth_is_deterministic_and_sliceable():
 
 
 def test_bpe_tokenizer_matches_reference_fixture(golden_dir):
-    """fitclip_amd.bpe vs ids produced by the reference's own SimpleTokenizer on the synthetic merges file."""
+    """The C++ tokenizer (fc_bpe_* behind fitclip_amd.bpe) and the Python restatement under oracle/ vs ids produced by
+    the reference's own SimpleTokenizer on the small synthetic merges file."""
     from fitclip_amd.bpe import ClipBpeTokenizer
+    from oracle.bpe_oracle import ClipBpeTokenizer as OracleBpe
     g = json.loads((golden_dir / "bpe_toy.json").read_text())
-    tok = ClipBpeTokenizer(str(golden_dir / "bpe_toy_merges.txt.gz"), context_length=16)
-    assert tok.vocab_size == g["vocab_size"]
+    path = str(golden_dir / "bpe_toy_merges.txt.gz")
+    for tok in (ClipBpeTokenizer(path, context_length=16), OracleBpe(path, context_length=16)):
+        assert tok.vocab_size == g["vocab_size"]
+        for text, ids, dec in zip(g["texts"], g["ids"], g["decoded"]):
+            assert tok.encode(text) == ids, text
+            assert tok.decode(ids) == dec
+        out = tok(g["texts"])["input_ids"]
+        sot, eot = g["vocab_size"] - 2, g["vocab_size"] - 1
+        assert out.shape == (len(g["texts"]), 16) and (out[:, 0] == sot).all()
+        long_row = out[4]  # 40 x's: truncated, EOT restored in the last slot (clip.tokenize(truncate=True))
+        assert int(long_row[-1]) == eot and int(long_row.max()) == eot
+        assert out[6][:3].tolist() == [sot, eot, 0]  # empty text
+
+
+def test_bpe_tokenizer_at_full_vocabulary_size(golden_dir, tmp_path):
+    """SURVEY 8(f) N2 at the real vocabulary size: a synthetic 48 894-merge file (regenerated from its seed; the
+    published file is not available offline) -> SOT 49406 / EOT 49407, the 49152-256-2 cut, and ids identical to the
+    reference's SimpleTokenizer (fixture) on 51 texts incl. contractions, digits, symbol runs, HTML entities, NBSP /
+    control white space, long-s / Kelvin-sign case folding, the special tokens inside a text, and a 160-word text that
+    must be cut to 77 with EOT in the last slot.  Random texts are cross-checked against the Python restatement."""
+    import random
+    import sys
+    sys.path.insert(0, str(golden_dir))
+    from synth_merges import write_synthetic_merges
+    from fitclip_amd.bpe import ClipBpeTokenizer
+    from oracle.bpe_oracle import ClipBpeTokenizer as OracleBpe
+    g = json.loads((golden_dir / "bpe_full.json").read_text())
+    path = str(tmp_path / "synthetic_full_merges.txt.gz")
+    words = write_synthetic_merges(path, seed=g["merges_seed"])
+    with __import__("gzip").open(path, "rt", encoding="utf-8") as f:
+        lines = f.read().split("\n")
+    assert len(lines) - 2 == g["n_merges"] == 48894
+    tok = ClipBpeTokenizer(path, context_length=77)
+    assert (tok.sot_token, tok.eot_token, tok.vocab_size) == (g["sot"], g["eot"], g["len_encoder"]) and g["sot"] == 49406
     for text, ids, dec in zip(g["texts"], g["ids"], g["decoded"]):
         assert tok.encode(text) == ids, text
-        assert tok.decode(ids) == dec
+        assert tok.decode(ids) == dec, text
     out = tok(g["texts"])["input_ids"]
-    sot, eot = tok.token_id["<|startoftext|>"], tok.token_id["<|endoftext|>"]
-    assert out.shape == (len(g["texts"]), 16) and (out[:, 0] == sot).all()
-    long_row = out[4]  # 40 x's: truncated, EOT restored in the last slot (clip.tokenize(truncate=True))
-    assert int(long_row[-1]) == eot and int(long_row.max()) == eot
-    empty = out[6]
-    assert empty[:3].tolist() == [sot, eot, 0]
+    ref_call = torch.tensor(g["slip_call_context77"])          # slip's own __call__: cut at 77 WITHOUT restoring EOT
+    assert out.shape == ref_call.shape == (len(g["texts"]), 77)
+    for row, ref_row, ids in zip(out, ref_call, g["ids"]):
+        if len(ids) + 2 <= 77:
+            assert torch.equal(row, ref_row)
+        else:                                                   # clip.tokenize(truncate=True): same, EOT in the last slot
+            assert torch.equal(row[:76], ref_row[:76]) and int(row[76]) == 49407
+    assert sum(len(ids) + 2 > 77 for ids in g["ids"]) >= 1
+    # one more line in the file changes nothing (the cut at 49152 - 256 - 2 merges)
+    longer = str(tmp_path / "longer.txt.gz")
+    with __import__("gzip").open(longer, "wt", encoding="utf-8") as f:
+        f.write("\n".join(lines[:-1] + ["q z", "z q"]) + "\n")
+    tok2 = ClipBpeTokenizer(longer, context_length=77)
+    assert (tok2.sot_token, tok2.eot_token) == (49406, 49407) and tok2.encode("qz zq") == tok.encode("qz zq")
+    oracle = OracleBpe(path, context_length=77)
+    rng = random.Random(11)
+    pool = words[:3000] + ["it's", "they're", "12", "3.5", "!!", "...", "(", ")", "&amp;", "\u00e9t\u00e9", "\u65e5\u672c\u8a9e", "'ll", "I'M"]
+    texts = [" ".join(rng.choice(pool) for _ in range(rng.randrange(0, 30))) for _ in range(300)]
+    for t in texts:
+        assert tok.encode(t) == oracle.encode(t), t
+    assert torch.equal(tok(texts)["input_ids"], oracle(texts)["input_ids"])
 
 
 def test_zero_shot_oracle_semantics():
