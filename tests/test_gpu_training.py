@@ -340,3 +340,41 @@ def test_training_step_at_one_ranks_share_of_config5(vitb16_state_dict):
         if k == "token_embedding.weight":
             continue                              # only the rows of tokens that occur move
         assert not torch.equal(module.student.params[o:o + cnt], before[o:o + cnt]), k
+
+
+def test_two_rank_training_step_equals_single_rank(tmp_path):
+    """The data-parallel training step (teacher_student.py:143: `all_gather(..., sync_grads=True)` + DDP): two fresh rank
+    processes (gloo group on ONE GPU; the collectives are staged through the host, the rest is the production path) each
+    hold half of the labeled and half of the unlabeled clips, gather the embeddings, compute the full-batch losses,
+    back-propagate the LOCAL rows of the gathered-embedding gradient and sum the parameter gradients over the ranks.
+    Loss, every gradient and the updated parameters must equal the single-process step over the whole batch."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    worker = str(Path(__file__).resolve().parent / "workers" / "train_two_ranks.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    r1 = subprocess.run([sys.executable, worker, "--out", one], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), worker, "--out", two], capture_output=True, text=True,
+                        timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    a, b = np.load(one), np.load(two)
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
+    ga, gb = torch.from_numpy(a["grads"]), torch.from_numpy(b["grads"])
+    assert float((ga - gb).abs().max()) < 1e-4 * float(ga.abs().max())
+    # per tensor as well (small gradients must not hide behind the largest one)
+    d = synth.TINY
+    off = 0
+    for name, shape in synth.parameter_shapes(d).items():
+        cnt = int(np.prod(shape))
+        sl = slice(off, off + cnt)
+        assert _rel(gb[sl], ga[sl]) < 2e-4, name
+        off += -(-cnt // 64) * 64
+    assert np.allclose(a["scale_grads"], b["scale_grads"], rtol=1e-4, atol=1e-7)
