@@ -131,7 +131,10 @@ def plant_retrieval_weights(sd, video, ids, dims, device, wrong_frac=0.3, block=
     cls = torch.cat(feats, dim=1)
     mu = cls.mean(0)
     _, _, vt = torch.linalg.svd(cls - mu, full_matrices=False)
-    out = {"visual.proj": vt[:E].T.float().contiguous(),
+    proj_v = torch.zeros((W, E), dtype=torch.float64)
+    r = min(E, vt.shape[0])                 # fewer frames than embedding dimensions: the remaining columns stay zero
+    proj_v[:, :r] = vt[:r].T
+    out = {"visual.proj": proj_v.float().contiguous(),
            "visual.ln_post.bias": (model.visual.ln_post.bias.detach().double().cpu() - mu).float()}
     model.visual.proj.data.copy_(out["visual.proj"].to(device))
     model.visual.ln_post.bias.data.copy_(out["visual.ln_post.bias"].to(device))
