@@ -425,9 +425,20 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     const int cn = std::min(chunk, n - off);
     const Scratch s = carve(static_cast<char*>(ws), cn, T, vw, h->esz, Kp);
     const float* f = frames + (size_t)off * 3 * R * R;
-    FC_TRY(launch_im2col(f, s.big, kind, cn, R, c.vision_patch_size, Kp, st));
-    FC_TRY(gemm(h, EPI_PATCH_F32, s.big, h->conv_w, nullptr, s.x, h->w("visual.positional_embedding"), cn * P, vw, Kp,
-                vw, P, st));
+    const int p = c.vision_patch_size;
+    if (kind == PREC_F32 && Kp == h->patch_k() && p % 4 == 0 && R % 4 == 0) {
+      // fp32 mode: the GEMM's LDS-DMA loader gathers the 16 x 16 x 3 patches straight from the NCHW frames (16-byte
+      // pieces of 4 pixels): the frames are read once, no im2col matrix is written to / re-read from HBM
+      GemmArgs a{};
+      a.A = f; a.W = h->conv_w; a.C = s.x; a.aux = h->w("visual.positional_embedding"); a.alpha = 1.f;
+      a.M = cn * P; a.N = vw; a.K = Kp; a.lda = Kp; a.ldw = Kp; a.ldc = vw; a.P = P; a.gR = R; a.gP = p;
+      ProfScope ps(h, st, kind, EPI_PATCH_F32, gemm_resolved_tile(kind, EPI_PATCH_F32, a, h->cfg.gemm_tile), a);
+      FC_TRY(launch_gemm(kind, EPI_PATCH_F32, a, h->cfg.gemm_tile, st));
+    } else {  // bf16 operands (the conversion pass IS the im2col pass) or a patch size that needs K padding (14)
+      FC_TRY(launch_im2col(f, s.big, kind, cn, R, p, Kp, st));
+      FC_TRY(gemm(h, EPI_PATCH_F32, s.big, h->conv_w, nullptr, s.x, h->w("visual.positional_embedding"), cn * P, vw,
+                  Kp, vw, P, st));
+    }
     const TowerEntry entry{h->w("visual.class_embedding"), h->w("visual.positional_embedding"),
                            h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias")};
     FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),

@@ -56,6 +56,9 @@ struct GemmArgs {
   int P;              // EPI_PATCH_F32: patches per image
   int nblock;         // pipelined kernel: N-tiles per L2-resident weight block (0 = all)
   int nsplit;         // pipelined kernel: XCD groups that split the N range (1, 2 or 4; 0 = 1)
+  // EPI_PATCH_F32 with T = float: gR > 0 makes A the FRAMES f32 [n, 3, gR, gR]; row m = (image, patch) and column
+  // k = (channel, py, px) of the im2col matrix are gathered by the LDS-DMA loader itself (no im2col pass in HBM).
+  int gR, gP;
 };
 
 // tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)

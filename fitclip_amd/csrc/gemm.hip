@@ -135,6 +135,12 @@ int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStr
     return fail(FC_EINVAL, "gemm: bias missing");
   if (epilogue == EPI_DGELU_T && (!a.aux || ((uintptr_t)a.aux & 15))) return fail(FC_EINVAL, "gemm: dgelu epilogue needs aux");
   if (epilogue == EPI_PATCH_F32 && (!a.aux || a.P <= 0)) return fail(FC_EINVAL, "gemm: patch epilogue needs pos/P");
+  if (a.gR > 0) {
+    const int G = a.gP > 0 ? a.gR / a.gP : 0;
+    if (epilogue != EPI_PATCH_F32 || precision != PREC_F32 || a.gP <= 0 || a.gP % 4 || a.gR % a.gP || a.gR % 4 ||
+        G * G != a.P || a.K != 3 * a.gP * a.gP)
+      return fail(FC_EINVAL, "gemm: patch gather needs the f32 patch-embed epilogue, patch %% 4 == 0 and K = 3 p^2");
+  }
   if (tile < 0 || tile > 3) return fail(FC_EINVAL, "gemm: tile=%d", tile);
   return precision == PREC_BF16 ? launch_epi<bf16>(epilogue, a, tile, stream)
                                 : launch_epi<float>(epilogue, a, tile, stream);

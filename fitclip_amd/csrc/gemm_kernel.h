@@ -126,6 +126,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
 
   // ---- per-lane staging sources
   const char* src[LPW];
+  // patch gather (EPI_PATCH_F32, f32, g.gR > 0): the A row of an (image, patch) pair is not contiguous - its 16-byte
+  // chunk `lchunk` of K-tile kt holds 4 consecutive pixels of one patch row: k = 32 kt + 4 lchunk = (c, py, px)
+  constexpr bool kGather = EPI == EPI_PATCH_F32 && sizeof(T) == 4;
+  constexpr int LPA_G = BM / 8 / NW;  // the first LPA_G pieces of a wave are activation rows
+  int lchunk[kGather ? LPA_G : 1];
   {
     const int rin = lane >> 3, pc = lane & 7;
 #pragma unroll
@@ -134,6 +139,16 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
       const int chunk = pc ^ ((row >> 1) & 7);
       if (row < BM) {
         const int gr = min((ABL == 2 ? 0 : m0) + row, g.M - 1);
+        if constexpr (kGather) {
+          if (g.gR > 0) {
+            const int G = g.gR / g.gP;
+            const int img = gr / g.P, pidx = gr - img * g.P, gy = pidx / G, gx = pidx - gy * G;
+            src[i] = reinterpret_cast<const char*>(g.A) +
+                     (((size_t)img * 3 * g.gR + (size_t)gy * g.gP) * g.gR + (size_t)gx * g.gP) * sizeof(float);
+            if (i < LPA_G) lchunk[i] = chunk;
+            continue;
+          }
+        }
         src[i] = reinterpret_cast<const char*>(g.A) + ((size_t)gr * g.lda) * sizeof(T) + chunk * 16;
       } else {
         const int gr = min((ABL == 2 ? 0 : n0) + row - BM, g.N - 1);
@@ -144,8 +159,16 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   auto stage_load = [&](int stage, int kt) {
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
+      const char* p = src[i] + (size_t)kt * ROWB;
+      if constexpr (kGather) {
+        if (g.gR > 0 && i < LPA_G) {
+          const int k = kt * BKE + lchunk[i] * 4, pp = g.gP * g.gP;
+          const int c = k / pp, rem = k - c * pp, py = rem / g.gP, px = rem - py * g.gP;
+          p = src[i] + (((size_t)c * g.gR + py) * g.gR + px) * sizeof(float);
+        }
+      }
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * ROWB),
+          (const __attribute__((address_space(1))) void*)p,
           (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (wave + i * NW) * 1024),
           16, 0, 0);
     }

@@ -365,17 +365,18 @@ def test_zero_shot_classification_matches_oracle(tiny_state_dict):
     assert pred["predictions"].tolist() == scores[:4].argmax(-1).tolist()
 
 
-@pytest.mark.parametrize("H,W", [(224, 224), (240, 320), (360, 202), (256, 256)])
-def test_device_preprocessing_matches_the_eval_transform(tiny_state_dict, H, W):
-    """fc_preprocess_u8 vs the plugin's own eval transform (torch on the CPU: BHWC->BCHW, /255, bicubic
-    resize of the shorter side, centre crop, CLIP mean/std - clip_video_text_encoder.py:125-133)."""
-    enc = _encoder(tiny_state_dict, "fp32")  # the transform does not depend on the weights
-    enc.model.visual.input_resolution = 224
+@pytest.mark.parametrize("H,W", [(224, 224), (240, 320), (360, 202), (256, 256), (90, 130)])
+def test_device_preprocessing_matches_the_eval_transform(H, W):
+    """fc_preprocess_u8 vs the float64 restatement of the reference's eval transform under oracle/
+    (BHWC->BCHW, /255, torchvision Resize(BICUBIC) of the shorter side, CenterCrop, CLIP mean/std -
+    clip_video_text_encoder.py:125-133)."""
+    from fitclip_amd.encoder import CLIP_MEAN, CLIP_STD
+    from oracle.transform_oracle import eval_transform
     frames = torch.randint(0, 256, (3, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(H * W))
-    want = enc.get_eval_transform(torch.float32)(frames)
-    got = ops.preprocess_u8(frames.to(DEV), 224, enc.mean, enc.std).cpu()
+    want = eval_transform(frames.numpy(), 224, CLIP_MEAN, CLIP_STD)
+    got = ops.preprocess_u8(frames.to(DEV), 224, CLIP_MEAN, CLIP_STD).cpu().numpy()
     assert got.shape == want.shape == (3, 3, 224, 224)
-    assert (got - want).abs().max() < 5e-5
+    assert np.abs(got - want).max() < 5e-5
 
 
 def test_encode_video_uint8_path(tiny_state_dict):

@@ -196,3 +196,26 @@ def test_zero_shot_oracle_semantics():
     scores = torch.tensor([[0.9, 0.1, 0.3], [0.2, 0.2, 0.8]])
     m = O.zero_shot_metrics(scores, torch.tensor([0, 1]))
     assert m["a1"] == 0.5 and m["a5"] == 1.0 and m["mr"] == 1.0
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (240, 320), (360, 202), (70, 64)])
+def test_plugin_eval_transform_matches_the_transform_oracle(H, W):
+    """The plugin's data-side `get_eval_transform` (torch on the CPU, what a dataset worker runs) vs the independent
+    float64 restatement of the torchvision semantics in oracle/transform_oracle.py."""
+    from fitclip_amd.encoder import CLIP_MEAN, CLIP_STD, ClipVideoTextEncoder
+    from oracle.transform_oracle import eval_transform
+
+    class _Visual:
+        input_resolution = 64
+
+    class _Model:
+        visual = _Visual()
+
+    enc = ClipVideoTextEncoder.__new__(ClipVideoTextEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.__dict__["model"] = _Model()
+    enc.mean, enc.std = CLIP_MEAN, CLIP_STD
+    frames = torch.randint(0, 256, (2, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(H + W))
+    got = enc.get_eval_transform(torch.float32)(frames).numpy()
+    want = eval_transform(frames.numpy(), 64, CLIP_MEAN, CLIP_STD)
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-4  # float32 source coordinates on the torch side
