@@ -376,7 +376,9 @@ def test_device_preprocessing_matches_the_eval_transform(H, W):
     want = eval_transform(frames.numpy(), 224, CLIP_MEAN, CLIP_STD)
     got = ops.preprocess_u8(frames.to(DEV), 224, CLIP_MEAN, CLIP_STD).cpu().numpy()
     assert got.shape == want.shape == (3, 3, 224, 224)
-    assert np.abs(got - want).max() < 5e-5
+    # the kernel computes source coordinates and tap weights in float32 (as torch's bicubic does): ~1e-4 on values in
+    # [-1.8, 2.2] against the float64 restatement
+    assert np.abs(got - want).max() < 2e-4
 
 
 def test_encode_video_uint8_path(tiny_state_dict):
