@@ -269,7 +269,9 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
 }
 
 int default_chunk(const fc_handle* h, int tower) {
-  if (tower == 0) return h->cfg.chunk_frames > 0 ? h->cfg.chunk_frames : 512;
+  // fp32: 1024 frames per pass (9456 tiles per c_fc launch = 36.9 rounds of the 256 CUs: 0.2 % tail, against 2.8 % at
+  // 512 frames; measured +1.7 % on the step).  bf16: 512 (profiles/r01: larger chunks do not pay there).
+  if (tower == 0) return h->cfg.chunk_frames > 0 ? h->cfg.chunk_frames : (h->cfg.precision == FC_PREC_F32 ? 1024 : 512);
   return h->cfg.chunk_texts > 0 ? h->cfg.chunk_texts : 1024;
 }
 

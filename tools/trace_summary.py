@@ -46,7 +46,7 @@ def main():
         labelled.append([label, dur])
     # visual-tower launches of the pipelined GEMMs run for > 80 us at chunk >= 256 frames; the text tower's for < 60 us
     # (fp32: visual >= 900 us, text <= 350 us)
-    cut = 600.0 if fp32 else 70.0
+    cut = 600.0 * chunk / 512 if fp32 else 70.0
     cut_small = 100.0 if fp32 else 40.0
     seq = 0
     for item in labelled:
