@@ -210,10 +210,19 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
       for (int i = 0; i < FM; ++i) xa[i] = *reinterpret_cast<const FragT*>(st + a_base + i * 16 * ROWB + off);
 #pragma unroll
       for (int j = 0; j < FN; ++j) wb[j] = *reinterpret_cast<const FragT*>(st + b_base + j * 16 * ROWB + off);
+      if constexpr (sizeof(T) == 4) {  // k-slot outermost: consecutive MFMAs hit different accumulators (see the pipelined kernel)
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) mma<T>(wb[j], xa[i], acc[i][j]);
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j][t], xa[i][t], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) mma<T>(wb[j], xa[i], acc[i][j]);
+      }
     }
   }
 
@@ -563,10 +572,24 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           for (int a = 0; a < 2; ++a) xp[0][a] = *reinterpret_cast<const FragT*>(nx + a_base + a * 16 * ROWB + foff[0]);
          }
         }
+        if constexpr (sizeof(T) == 4) {
+          // fp32: a fragment pair is FOUR chained v_mfma_f32_16x16x4_f32 on one accumulator (40-cycle dependent latency
+          // against a 32-cycle issue interval).  Issue them k-slot by k-slot across the group's 2 * FN accumulators, so
+          // consecutive MFMAs are independent and ONE wave can keep the pipe full while its SIMD partner waits.  Each
+          // accumulator still sees its products in the same order: results are bit-identical.
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) mma<T>(wb[s & 1][j], xp[u & 1][a], acc[2 * p + a][j]);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int j = 0; j < FN; ++j)
+                acc[2 * p + a][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s & 1][j][t], xp[u & 1][a][t], acc[2 * p + a][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mma<T>(wb[s & 1][j], xp[u & 1][a], acc[2 * p + a][j]);
+        }
         if constexpr (SCHED > 0 && ABL != 1 && u + 1 < NG) {
           constexpr bool any = piece_slot(SCHED, 0) == u || piece_slot(SCHED, 1) == u || piece_slot(SCHED, 2) == u ||
                                piece_slot(SCHED, 3) == u || piece_slot(SCHED, 4) == u || piece_slot(SCHED, 5) == u ||
