@@ -59,6 +59,7 @@ SIGNATURES = {
     "fc_group_mean": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "fc_nce_loss": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "fc_kd_loss": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "fc_kd_loss_rect": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "fc_wise": (_i32, [_vp, _vp, _f64, _vp, _sz, _vp]),
     "fc_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fc_layernorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
@@ -76,8 +77,8 @@ SIGNATURES = {
     "fc_encode_text_backward": (_i32, [_vp, _vp, _vp, _i32, _vp, _sz, _vp, _sz, _i32, _vp]),
     "fc_pool_normalize_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "fc_nce_loss_backward": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp]),
-    "fc_kd_loss_backward": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp]),
-    "fc_kd_teacher_scale_grad": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "fc_kd_loss_backward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "fc_kd_teacher_scale_grad": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "fc_gemm_tn_scratch_bytes": (_sz, [_i32, _i32, _i32]),
     "fc_gemm_tn": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp, _sz, _vp]),
     "fc_attention_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -512,7 +512,11 @@ int fc_group_mean(const float* in, float* out, int32_t n_groups, int32_t group, 
 }
 int fc_nce_loss(const float* s, int32_t n, float* out, float* ws, fc_stream st) { return launch_nce_loss(s, n, out, ws, st); }
 int fc_kd_loss(const float* s, const float* t, int32_t n, float* out, float* ws, fc_stream st) {
-  return launch_kd_loss(s, t, n, out, ws, st);
+  return launch_kd_loss(s, t, n, n, out, ws, st);
+}
+int fc_kd_loss_rect(const float* s, const float* t, int32_t rows, int32_t cols, float* out, float* ws, fc_stream st) {
+  if (!s || !t || !out || !ws) return fail(FC_EINVAL, "fc_kd_loss_rect: null argument");
+  return launch_kd_loss(s, t, rows, cols, out, ws, st);
 }
 int fc_wise(const float* a, const float* b, double w, float* out, size_t n, fc_stream st) {
   return launch_wise(a, b, w, out, n, st);

@@ -300,12 +300,14 @@ __device__ __forceinline__ float block_max_b(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// lse[line] = logsumexp(line): blocks [0, n) rows, [n, 2n) columns
-__global__ void __launch_bounds__(256) lse_lines_kernel(const float* __restrict__ s, int n, float* __restrict__ lse) {
+// lse[line] = logsumexp(line) of s [R, C]: blocks [0, R) rows, [R, R + C) columns
+__global__ void __launch_bounds__(256) lse_lines_kernel(const float* __restrict__ s, int R, int C,
+                                                        float* __restrict__ lse) {
   __shared__ float red[4];
-  const bool col = blockIdx.x >= n;
-  const int i = col ? blockIdx.x - n : blockIdx.x;
-  const long sl = col ? 1 : n, se = col ? n : 1;
+  const bool col = blockIdx.x >= R;
+  const int i = col ? blockIdx.x - R : blockIdx.x;
+  const int n = col ? R : C;
+  const long sl = col ? 1 : C, se = col ? C : 1;
   const float* line = s + i * sl;
   float mx = -__builtin_inff();
   for (int j = threadIdx.x; j < n; j += 256) mx = fmaxf(mx, line[j * se]);
@@ -316,23 +318,26 @@ __global__ void __launch_bounds__(256) lse_lines_kernel(const float* __restrict_
   if (threadIdx.x == 0) lse[blockIdx.x] = mx + logf(sum);
 }
 
-// dS[i,j] = c/n * ( softmax_row(S)[i,j] + softmax_col(S)[i,j] - target ),  target = 2 delta_ij  (NCE, loss.py:13-26)
-//                                                     or softmax_row(T)[i,j] + softmax_col(T)[i,j]  (KD, loss.py:29-39)
+// dS[i,j] = c ( (softmax_row(S)[i,j] - tr) / R + (softmax_col(S)[i,j] - tc) / C ) for S [R, C];
+//   NCE (square, loss.py:13-26): tr = tc = delta_ij;   KD (loss.py:29-39): tr / tc = softmax_row / softmax_col of T
 __global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__ s, const float* __restrict__ lse,
                                                        const float* __restrict__ t, const float* __restrict__ lse_t,
-                                                       int n, float coef, float* __restrict__ ds) {
-  const size_t total = (size_t)n * n;
+                                                       int R, int C, float coef, float* __restrict__ ds) {
+  const size_t total = (size_t)R * C;
+  const float cr = coef / (float)R, cc = coef / (float)C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+    const int i = (int)(idx / C), j = (int)(idx - (size_t)i * C);
     const float v = s[idx];
-    float grad = expf(v - lse[i]) + expf(v - lse[n + j]);
+    float gr = expf(v - lse[i]), gc = expf(v - lse[R + j]);
     if (t) {
       const float tv = t[idx];
-      grad -= expf(tv - lse_t[i]) + expf(tv - lse_t[n + j]);
+      gr -= expf(tv - lse_t[i]);
+      gc -= expf(tv - lse_t[R + j]);
     } else if (i == j) {
-      grad -= 2.f;
+      gr -= 1.f;
+      gc -= 1.f;
     }
-    ds[idx] = grad * coef;
+    ds[idx] = gr * cr + gc * cc;
   }
 }
 
@@ -341,12 +346,13 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__
 // (what the teacher-student temperature, which multiplies every teacher score, receives through the teacher scores).
 __global__ void __launch_bounds__(256) kd_teacher_lines_kernel(const float* __restrict__ s, const float* __restrict__ t,
                                                                const float* __restrict__ lse,
-                                                               const float* __restrict__ lse_t, int n,
+                                                               const float* __restrict__ lse_t, int R, int C,
                                                                float* __restrict__ out) {
   __shared__ float red[4];
-  const bool col = blockIdx.x >= n;
-  const int i = col ? blockIdx.x - n : blockIdx.x;
-  const long sl = col ? 1 : n, se = col ? n : 1;
+  const bool col = blockIdx.x >= R;
+  const int i = col ? blockIdx.x - R : blockIdx.x;
+  const int n = col ? R : C;
+  const long sl = col ? 1 : C, se = col ? C : 1;
   const float* ls = s + i * sl;
   const float* lt = t + i * sl;
   const float a = lse[blockIdx.x], b = lse_t[blockIdx.x];
@@ -365,13 +371,16 @@ __global__ void __launch_bounds__(256) kd_teacher_lines_kernel(const float* __re
   w2 = block_sum_b(w2, red);
   if (threadIdx.x == 0) out[blockIdx.x] = w1 - kl * w2;
 }
-__global__ void __launch_bounds__(256) sum_over_n_kernel(const float* __restrict__ a, int count, int n,
-                                                         float* __restrict__ out) {
+// out[0] = sum(a[0..R)) / R + sum(a[R..R+C)) / C
+__global__ void __launch_bounds__(256) sum_lines_kernel(const float* __restrict__ a, int R, int C,
+                                                        float* __restrict__ out) {
   __shared__ float red[4];
-  float s = 0.f;
-  for (int j = threadIdx.x; j < count; j += 256) s += a[j];
-  s = block_sum_b(s, red);
-  if (threadIdx.x == 0) out[0] = s / (float)n;
+  float sr = 0.f, sc = 0.f;
+  for (int j = threadIdx.x; j < R; j += 256) sr += a[j];
+  for (int j = threadIdx.x; j < C; j += 256) sc += a[R + j];
+  sr = block_sum_b(sr, red);
+  sc = block_sum_b(sc, red);
+  if (threadIdx.x == 0) out[0] = sr / (float)R + sc / (float)C;
 }
 
 // out[0] = beta * out[0] + alpha * sum_i a[i] b[i]   (single block, fixed order)
@@ -502,26 +511,28 @@ int launch_pool_normalize_backward(const float* z, const float* dout, float* dz,
   return FC_OK;
 }
 
-// ws: 2 n floats (NCE) or 4 n floats (KD)
-int launch_loss_backward(const float* scores, const float* teacher, int n, float coef, float* dscores, float* ws,
+// scores [R, C]; ws: (R + C) floats (NCE) or 2 (R + C) floats (KD)
+int launch_loss_backward(const float* scores, const float* teacher, int R, int C, float coef, float* dscores, float* ws,
                          hipStream_t st) {
-  if (n <= 0) return fail(FC_EINVAL, "loss backward: n=%d", n);
-  hipLaunchKernelGGL(lse_lines_kernel, dim3(2 * n), dim3(256), 0, st, scores, n, ws);
-  if (teacher) hipLaunchKernelGGL(lse_lines_kernel, dim3(2 * n), dim3(256), 0, st, teacher, n, ws + 2 * n);
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3(flat_blocks_b((size_t)n * n)), dim3(256), 0, st, scores, ws, teacher,
-                     ws + 2 * n, n, coef / (float)n, dscores);
+  if (R <= 0 || C <= 0) return fail(FC_EINVAL, "loss backward: %d x %d", R, C);
+  if (!teacher && R != C) return fail(FC_EINVAL, "loss backward: the NCE loss needs a square score matrix");
+  hipLaunchKernelGGL(lse_lines_kernel, dim3(R + C), dim3(256), 0, st, scores, R, C, ws);
+  if (teacher) hipLaunchKernelGGL(lse_lines_kernel, dim3(R + C), dim3(256), 0, st, teacher, R, C, ws + R + C);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(flat_blocks_b((size_t)R * C)), dim3(256), 0, st, scores, ws, teacher,
+                     ws + R + C, R, C, coef, dscores);
   FC_CHECK_LAUNCH("loss backward");
   return FC_OK;
 }
 
-// out[0] = sum_ij dKD/dteacher_ij * teacher_ij  ("batchmean", rows + columns); ws: 6 n floats
-int launch_kd_teacher_scale_grad(const float* scores, const float* teacher, int n, float* out, float* ws,
+// out[0] = sum_ij dKD/dteacher_ij * teacher_ij  ("batchmean", rows + columns); ws: 3 (R + C) floats
+int launch_kd_teacher_scale_grad(const float* scores, const float* teacher, int R, int C, float* out, float* ws,
                                  hipStream_t st) {
-  if (n <= 0) return fail(FC_EINVAL, "kd teacher grad: n=%d", n);
-  hipLaunchKernelGGL(lse_lines_kernel, dim3(2 * n), dim3(256), 0, st, scores, n, ws);
-  hipLaunchKernelGGL(lse_lines_kernel, dim3(2 * n), dim3(256), 0, st, teacher, n, ws + 2 * n);
-  hipLaunchKernelGGL(kd_teacher_lines_kernel, dim3(2 * n), dim3(256), 0, st, scores, teacher, ws, ws + 2 * n, n, ws + 4 * n);
-  hipLaunchKernelGGL(sum_over_n_kernel, dim3(1), dim3(256), 0, st, ws + 4 * n, 2 * n, n, out);
+  if (R <= 0 || C <= 0) return fail(FC_EINVAL, "kd teacher grad: %d x %d", R, C);
+  const int L = R + C;
+  hipLaunchKernelGGL(lse_lines_kernel, dim3(L), dim3(256), 0, st, scores, R, C, ws);
+  hipLaunchKernelGGL(lse_lines_kernel, dim3(L), dim3(256), 0, st, teacher, R, C, ws + L);
+  hipLaunchKernelGGL(kd_teacher_lines_kernel, dim3(L), dim3(256), 0, st, scores, teacher, ws, ws + L, R, C, ws + 2 * L);
+  hipLaunchKernelGGL(sum_lines_kernel, dim3(1), dim3(256), 0, st, ws + 2 * L, R, C, out);
   FC_CHECK_LAUNCH("kd teacher grad");
   return FC_OK;
 }

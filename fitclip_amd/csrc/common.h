@@ -106,7 +106,8 @@ int launch_wise(const float* a, const float* b, double w, float* out, size_t n, 
 int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, const int32_t* targets,
                  int32_t* ranks, hipStream_t stream);
 int launch_nce_loss(const float* scores, int n, float* out, float* ws, hipStream_t stream);
-int launch_kd_loss(const float* scores, const float* teacher, int n, float* out, float* ws, hipStream_t stream);
+int launch_kd_loss(const float* scores, const float* teacher, int rows, int cols, float* out, float* ws,
+                   hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------- training step
 // attention backward (attention_bwd.hip); qkv / o are the forward's input / output, d_o the gradient of o
@@ -133,10 +134,10 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, double 
                  double wd, int step, hipStream_t st);
 int launch_pool_normalize_backward(const float* z, const float* dout, float* dz, int n_clips, int frames, int dim,
                                    hipStream_t st);
-int launch_loss_backward(const float* scores, const float* teacher, int n, float coef, float* dscores, float* ws,
+int launch_loss_backward(const float* scores, const float* teacher, int R, int C, float coef, float* dscores, float* ws,
                          hipStream_t st);
 int launch_dot(const float* a, const float* b, size_t n, float alpha, float beta, float* out, hipStream_t st);
-int launch_kd_teacher_scale_grad(const float* scores, const float* teacher, int n, float* out, float* ws,
+int launch_kd_teacher_scale_grad(const float* scores, const float* teacher, int R, int C, float* out, float* ws,
                                  hipStream_t st);
 // sums[t, :] = sum_i g[i * S + t, :] into scratch (S * D floats), then out_pos = beta out_pos + sums and, if given,
 // out_row0 = beta out_row0 + sums[0]

@@ -94,18 +94,18 @@ __global__ void __launch_bounds__(256) kd_lines_kernel(const float* __restrict__
   if (threadIdx.x == 0) out[i] = kl;
 }
 
-// out[0] = (sum(a[0..n)) + sum(b[0..n))) / n     (mean over rows + mean over columns; "batchmean" for the KD loss)
-__global__ void __launch_bounds__(256) finish_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          int n, float* __restrict__ out) {
+// out[0] = sum(a[0..na)) / na + sum(b[0..nb)) / nb   (mean over rows + mean over columns; "batchmean" of the KD loss
+// divides each direction by ITS number of lines: F.kl_div(input, ...) / input.size(0), loss.py:29-39)
+__global__ void __launch_bounds__(256) finish_mean_kernel(const float* __restrict__ a, int na,
+                                                          const float* __restrict__ b, int nb,
+                                                          float* __restrict__ out) {
   __shared__ float red[4];
   float sa = 0.f, sb = 0.f;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    sa += a[j];
-    sb += b[j];
-  }
+  for (int j = threadIdx.x; j < na; j += 256) sa += a[j];
+  for (int j = threadIdx.x; j < nb; j += 256) sb += b[j];
   sa = block_sum(sa, red);
   sb = block_sum(sb, red);
-  if (threadIdx.x == 0) out[0] = sa / (float)n + sb / (float)n;
+  if (threadIdx.x == 0) out[0] = sa / (float)na + sb / (float)nb;
 }
 
 }  // namespace
@@ -125,16 +125,18 @@ int launch_nce_loss(const float* scores, int n, float* out, float* ws, hipStream
   if (n <= 0) return fail(FC_EINVAL, "nce_loss: n=%d", n);
   hipLaunchKernelGGL(nce_lines_kernel, dim3(n), dim3(256), 0, stream, scores, n, (long)n, 1L, ws);
   hipLaunchKernelGGL(nce_lines_kernel, dim3(n), dim3(256), 0, stream, scores, n, 1L, (long)n, ws + n);
-  hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, stream, ws, ws + n, n, out);
+  hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, stream, ws, n, ws + n, n, out);
   FC_CHECK_LAUNCH("nce_loss");
   return FC_OK;
 }
 
-int launch_kd_loss(const float* scores, const float* teacher, int n, float* out, float* ws, hipStream_t stream) {
-  if (n <= 0) return fail(FC_EINVAL, "kd_loss: n=%d", n);
-  hipLaunchKernelGGL(kd_lines_kernel, dim3(n), dim3(256), 0, stream, scores, teacher, n, (long)n, 1L, ws);
-  hipLaunchKernelGGL(kd_lines_kernel, dim3(n), dim3(256), 0, stream, scores, teacher, n, 1L, (long)n, ws + n);
-  hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, stream, ws, ws + n, n, out);
+// scores / teacher [rows, cols] contiguous (rows = videos, cols = texts or prompts); ws: rows + cols floats
+int launch_kd_loss(const float* scores, const float* teacher, int rows, int cols, float* out, float* ws,
+                   hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return fail(FC_EINVAL, "kd_loss: %d x %d", rows, cols);
+  hipLaunchKernelGGL(kd_lines_kernel, dim3(rows), dim3(256), 0, stream, scores, teacher, cols, (long)cols, 1L, ws);
+  hipLaunchKernelGGL(kd_lines_kernel, dim3(cols), dim3(256), 0, stream, scores, teacher, rows, 1L, (long)cols, ws + rows);
+  hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, stream, ws, rows, ws + rows, cols, out);
   FC_CHECK_LAUNCH("kd_loss");
   return FC_OK;
 }

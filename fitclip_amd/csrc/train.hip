@@ -393,17 +393,18 @@ int fc_pool_normalize_backward(const float* z, const float* dout, float* dz, int
 }
 int fc_nce_loss_backward(const float* scores, int32_t n, float coef, float* dscores, float* ws, fc_stream st) {
   if (!scores || !dscores || !ws) return fail(FC_EINVAL, "fc_nce_loss_backward: null argument");
-  return launch_loss_backward(scores, nullptr, n, coef, dscores, ws, st);
+  return launch_loss_backward(scores, nullptr, n, n, coef, dscores, ws, st);
 }
-int fc_kd_loss_backward(const float* scores, const float* teacher, int32_t n, float coef, float* dscores, float* ws,
-                        fc_stream st) {
+int fc_kd_loss_backward(const float* scores, const float* teacher, int32_t rows, int32_t cols, float coef,
+                        float* dscores, float* ws, fc_stream st) {
   if (!scores || !teacher || !dscores || !ws) return fail(FC_EINVAL, "fc_kd_loss_backward: null argument");
-  return launch_loss_backward(scores, teacher, n, coef, dscores, ws, st);
+  return launch_loss_backward(scores, teacher, rows, cols, coef, dscores, ws, st);
 }
 
-int fc_kd_teacher_scale_grad(const float* scores, const float* teacher, int32_t n, float* out, float* ws, fc_stream st) {
+int fc_kd_teacher_scale_grad(const float* scores, const float* teacher, int32_t rows, int32_t cols, float* out, float* ws,
+                             fc_stream st) {
   if (!scores || !teacher || !out || !ws) return fail(FC_EINVAL, "fc_kd_teacher_scale_grad: null argument");
-  return launch_kd_teacher_scale_grad(scores, teacher, n, out, ws, st);
+  return launch_kd_teacher_scale_grad(scores, teacher, rows, cols, out, ws, st);
 }
 
 size_t fc_gemm_tn_scratch_bytes(int32_t M, int32_t N1, int32_t N2) { return 1024 + gemm_tn_scratch_bytes(M, N1, N2); }

@@ -249,14 +249,18 @@ def nce_loss(scores: torch.Tensor) -> torch.Tensor:
 
 
 def teacher_student_nce_loss(scores: torch.Tensor, teacher_scores: torch.Tensor) -> torch.Tensor:
-    """aligner/loss.py:29-39 with reduction "batchmean" (teacher_student.py:72-73)."""
-    scores, teacher_scores = _square(scores, "scores"), _square(teacher_scores, "teacher_scores")
-    n = scores.shape[0]
+    """aligner/loss.py:29-39 with reduction "batchmean" (teacher_student.py:72-73); [rows, cols] matrices (square for
+    video-caption batches, rectangular for the videos x prompts variant)."""
+    scores = _dev(scores.contiguous(), "scores", torch.float32)
+    teacher_scores = _dev(teacher_scores.contiguous(), "teacher_scores", torch.float32)
+    if scores.dim() != 2 or scores.shape != teacher_scores.shape:
+        raise ValueError("scores and teacher_scores must be 2-D and of the same shape")
+    rows, cols = scores.shape
     out = torch.empty((1,), dtype=torch.float32, device=scores.device)
-    ws = torch.empty((2 * n,), dtype=torch.float32, device=scores.device)
+    ws = torch.empty((rows + cols,), dtype=torch.float32, device=scores.device)
     with torch.cuda.device(scores.device):
-        _lib.check(_lib.load().fc_kd_loss(scores.data_ptr(), teacher_scores.data_ptr(), n, out.data_ptr(),
-                                          ws.data_ptr(), _lib.current_stream()), "fc_kd_loss")
+        _lib.check(_lib.load().fc_kd_loss_rect(scores.data_ptr(), teacher_scores.data_ptr(), rows, cols, out.data_ptr(),
+                                               ws.data_ptr(), _lib.current_stream()), "fc_kd_loss_rect")
     return out[0]
 
 

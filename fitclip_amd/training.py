@@ -211,7 +211,7 @@ class TeacherStudentTrainer(TeacherStudentModule):
                  dataset_names: Iterable[str] = ("labeled", "unlabeled"), init_temperature: float = 0.05,
                  min_temperature: float = 0.001, fit_temperature: bool = True, lr: float = 3e-6,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 **trainer_kwargs: Any) -> None:
+                 prompts: Optional[Iterable[str]] = None, **trainer_kwargs: Any) -> None:
         super().__init__(encoder, teacher, init_temperature, min_temperature)
         self.dataset_names = list(dataset_names)
         assert len(self.dataset_names) == 2, "The current implementation needs exactly 2 datasets."  # :57
@@ -222,7 +222,15 @@ class TeacherStudentTrainer(TeacherStudentModule):
             self.dataset_loss_share.update((name, (1 - labeled_dataset_loss_share) / (len(self.dataset_names) - 1))
                                            for name in self.dataset_names if name != labeled_dataset_name)
         self.labeled_dataset_name = labeled_dataset_name
+        self.unlabeled_dataset_name = next(k for k in self.dataset_names if k != labeled_dataset_name)
         self.fit_temperature = fit_temperature
+        # `prompts` (teacher_student.py:79-91): the unlabeled videos are scored against this fixed list instead of
+        # their own captions; each tower's tokenizer tokenizes it once
+        self.tokenized_prompts = self.teacher_tokenized_prompts = None
+        if prompts is not None:
+            prompts = list(prompts)
+            self.tokenized_prompts = encoder.get_tokenizer()(prompts)["input_ids"]
+            self.teacher_tokenized_prompts = teacher.get_tokenizer()(prompts)["input_ids"]
         self.student = StudentTrainer(encoder, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **trainer_kwargs)
         dev = self.student.params.device
         # [logit_scale, teacher_student_logit_scale]: value, grad, AdamW moments (the reference hands them to the same
@@ -238,20 +246,34 @@ class TeacherStudentTrainer(TeacherStudentModule):
     # ------------------------------------------------------------------------------------------------ training_step
     def training_step(self, batch: Mapping[str, Any]) -> Dict[str, Tuple[Tuple[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]]:
         """Student (activations kept) and teacher forward over the whole local batch, split per dataset
-        (teacher_student.py:99-140; the `prompts` variant, which scores videos against a fixed prompt list, is not
-        part of this path)."""
+        (teacher_student.py:99-140).  With `prompts` the captions of the unlabeled part are replaced by the prompt list
+        before the forward, so that part has `len(prompts)` text rows for its videos."""
         keys, lengths = _lengths(batch["dataset"])
         assert len(keys) == len(self.dataset_names), "All datasets should be present in each batch."
-        sv, st = self.student.forward(batch["video_student"], batch["text_student"])
+        text_student, text_teacher = batch["text_student"]["input_ids"], batch["text_teacher"]["input_ids"]
+        text_lengths = list(lengths)
+        if self.tokenized_prompts is not None:
+            idx = keys.index(self.unlabeled_dataset_name)
+            start, end = sum(lengths[:idx]), sum(lengths[:idx + 1])
+            dev = text_student.device
+
+            def replace(ids: torch.Tensor, new: torch.Tensor) -> torch.Tensor:  # _replace_in_tokenized_text, equal widths
+                assert ids.shape[1] == new.shape[1], "prompts and captions must share the context length"
+                return torch.cat((ids[:start], new.to(device=dev, dtype=ids.dtype), ids[end:]))
+
+            text_student = replace(text_student, self.tokenized_prompts)
+            text_teacher = replace(text_teacher, self.teacher_tokenized_prompts)
+            text_lengths[idx] = self.tokenized_prompts.shape[0]
+        sv, st = self.student.forward(batch["video_student"], {"input_ids": text_student})
         with torch.no_grad():
-            tv, tt = self.teacher(video=batch["video_teacher"], text=batch["text_teacher"])
-        out, start = {}, 0
-        for key, n in zip(keys, lengths):
-            sl = slice(start, start + n)
-            out[key] = ((sv[sl], st[sl]), (tv[sl], tt[sl]))
-            start += n
-        self._layout = [(k, n) for k, n in zip(keys, lengths)]
-        self._batch_rows = start
+            tv, tt = self.teacher(video=batch["video_teacher"], text={"input_ids": text_teacher})
+        out, v0, t0 = {}, 0, 0
+        self._layout = []
+        for key, nv, nt in zip(keys, lengths, text_lengths):
+            out[key] = ((sv[v0:v0 + nv], st[t0:t0 + nt]), (tv[v0:v0 + nv], tt[t0:t0 + nt]))
+            self._layout.append((key, nv, nt))
+            v0, t0 = v0 + nv, t0 + nt
+        self._rows = (v0, t0)
         return out
 
     # -------------------------------------------------------------------------------------------- training_step_end
@@ -262,57 +284,60 @@ class TeacherStudentTrainer(TeacherStudentModule):
         rank, world = D.world()
         dev = self.student.params.device
         e = self.encoder.model.dims.embed_dim
-        d_video = torch.zeros((self._batch_rows, e), dtype=torch.float32, device=dev)
-        d_text = torch.zeros_like(d_video)
+        d_video = torch.zeros((self._rows[0], e), dtype=torch.float32, device=dev)
+        d_text = torch.zeros((self._rows[1], e), dtype=torch.float32, device=dev)
         self.scale_grads.zero_()
         ls, ts_ls = float(self.scales[0]), float(self.scales[1])
         scale, ts_scale = math.exp(ls), math.exp(ts_ls)
-        total, start = 0.0, 0
+        total, v0, t0 = 0.0, 0, 0
         self.last_losses = {}
         with torch.cuda.device(dev):
             stream = _lib.current_stream()
-            for name, n_local in self._layout:
+            for name, nv, nt in self._layout:
                 (v, t), (tv, tt) = output[name]
-                counts = [n_local] * world
-                v_all, t_all, tv_all, tt_all = D.all_gather_many((v.contiguous(), t.contiguous(), tv.contiguous(),
-                                                                  tt.contiguous()), counts)
-                n = v_all.shape[0]
+                # one collective per distinct row count (one in all when videos and texts pair up)
+                if nv == nt:
+                    v_all, t_all, tv_all, tt_all = D.all_gather_many((v.contiguous(), t.contiguous(), tv.contiguous(),
+                                                                      tt.contiguous()), [nv] * world)
+                else:
+                    v_all, tv_all = D.all_gather_many((v.contiguous(), tv.contiguous()), [nv] * world)
+                    t_all, tt_all = D.all_gather_many((t.contiguous(), tt.contiguous()), [nt] * world)
+                rows, cols = v_all.shape[0], t_all.shape[0]
                 share = self.dataset_loss_share[name]
                 scores = ops.similarity(v_all, t_all, alpha=scale).contiguous()
                 dscores = torch.empty_like(scores)
-                ws = torch.empty(6 * n, dtype=torch.float32, device=dev)
+                ws = torch.empty(3 * (rows + cols), dtype=torch.float32, device=dev)
                 if name == self.labeled_dataset_name:
                     loss = ops.nce_loss(scores)
-                    _lib.check(lib.fc_nce_loss_backward(scores.data_ptr(), n, share, dscores.data_ptr(), ws.data_ptr(),
-                                                        stream), "fc_nce_loss_backward")
+                    _lib.check(lib.fc_nce_loss_backward(scores.data_ptr(), rows, share, dscores.data_ptr(),
+                                                        ws.data_ptr(), stream), "fc_nce_loss_backward")
                 else:
                     teacher_scores = ops.similarity(tv_all, tt_all, alpha=ts_scale).contiguous()
                     kd = ops.teacher_student_nce_loss(scores, teacher_scores)
                     loss = kd * ts_scale ** 2
-                    _lib.check(lib.fc_kd_loss_backward(scores.data_ptr(), teacher_scores.data_ptr(), n,
+                    _lib.check(lib.fc_kd_loss_backward(scores.data_ptr(), teacher_scores.data_ptr(), rows, cols,
                                                        share * ts_scale ** 2, dscores.data_ptr(), ws.data_ptr(), stream),
                                "fc_kd_loss_backward")
                     if self.fit_temperature:
                         # d/d(ts_ls) [kd(S, e^ts_ls X) e^(2 ts_ls)] = e^(2 ts_ls) (sum dkd/dT * T + 2 kd)
                         tmp = torch.empty(1, dtype=torch.float32, device=dev)
-                        _lib.check(lib.fc_kd_teacher_scale_grad(scores.data_ptr(), teacher_scores.data_ptr(), n,
+                        _lib.check(lib.fc_kd_teacher_scale_grad(scores.data_ptr(), teacher_scores.data_ptr(), rows, cols,
                                                                 tmp.data_ptr(), ws.data_ptr(), stream),
                                    "fc_kd_teacher_scale_grad")
                         self.scale_grads[1] += share * ts_scale ** 2 * (tmp[0] + 2.0 * kd)
                 if self.fit_temperature:  # scores = e^ls X  =>  d loss / d ls = sum(dscores * scores)
-                    _lib.check(lib.fc_dot(dscores.data_ptr(), scores.data_ptr(), n * n, 1.0, 1.0,
+                    _lib.check(lib.fc_dot(dscores.data_ptr(), scores.data_ptr(), rows * cols, 1.0, 1.0,
                                           self.scale_grads.data_ptr(), stream), "fc_dot")
                 # scores = scale V T^T  =>  dV = scale dS T,  dT = scale dS^T V   (full gathered matrices; local rows kept)
-                dscores_t = torch.empty_like(dscores)
-                _lib.check(lib.fc_transpose(dscores.data_ptr(), dscores_t.data_ptr(), n, n, stream), "fc_transpose")
+                dscores_t = torch.empty((cols, rows), dtype=torch.float32, device=dev)
+                _lib.check(lib.fc_transpose(dscores.data_ptr(), dscores_t.data_ptr(), rows, cols, stream), "fc_transpose")
                 dv_all = ops.gemm_tn(dscores_t, t_all, alpha=scale)
                 dt_all = ops.gemm_tn(dscores, v_all, alpha=scale)
-                lo = rank * n_local
-                d_video[start:start + n_local] = dv_all[lo:lo + n_local]
-                d_text[start:start + n_local] = dt_all[lo:lo + n_local]
+                d_video[v0:v0 + nv] = dv_all[rank * nv:(rank + 1) * nv]
+                d_text[t0:t0 + nt] = dt_all[rank * nt:(rank + 1) * nt]
                 self.last_losses[name] = float(loss)
                 total += share * self.last_losses[name]
-                start += n_local
+                v0, t0 = v0 + nv, t0 + nt
         self._pending = (d_video, d_text)
         return total
 

@@ -132,6 +132,10 @@ FC_API int fc_ranks_of(const float* scores, int32_t ld, int32_t n_rows, int32_t 
 FC_API int fc_group_mean(const float* in, float* out, int32_t n_groups, int32_t group, int32_t dim, fc_stream stream);
 FC_API int fc_nce_loss(const float* scores, int32_t n, float* out, float* ws, fc_stream stream);
 FC_API int fc_kd_loss(const float* scores, const float* teacher_scores, int32_t n, float* out, float* ws, fc_stream stream);
+/* the same on [rows, cols] matrices (videos x prompts, teacher_student.py:111-138): each direction's "batchmean" divides
+ * by its own number of lines; ws: rows + cols floats */
+FC_API int fc_kd_loss_rect(const float* scores, const float* teacher_scores, int32_t rows, int32_t cols, float* out,
+                    float* ws, fc_stream stream);
 
 /* ---- WiSE (aligner/wise.py:16): out = (1 - weight_for_2) * a + weight_for_2 * b over n floats ------------------ */
 FC_API int fc_wise(const float* a, const float* b, double weight_for_2, float* out, size_t n, fc_stream stream);
@@ -188,15 +192,15 @@ FC_API int fc_encode_text_backward(fc_handle* h, const int64_t* ids, const float
  * output, d_out [n_clips, dim] -> d_z [n_clips * frames, dim] */
 FC_API int fc_pool_normalize_backward(const float* z, const float* d_out, float* d_z, int32_t n_clips, int32_t frames,
                                int32_t dim, fc_stream stream);
-/* d_scores = coef * dLoss/dscores of fc_nce_loss / fc_kd_loss (aligner/loss.py:13-39, "mean" / "batchmean");
- * ws: 2 n (NCE) or 4 n (KD) floats */
+/* d_scores = coef * dLoss/dscores of fc_nce_loss ([n, n]) / fc_kd_loss(_rect) ([rows, cols]) (aligner/loss.py:13-39,
+ * "mean" / "batchmean"); ws: 2 n (NCE) or 2 (rows + cols) (KD) floats */
 FC_API int fc_nce_loss_backward(const float* scores, int32_t n, float coef, float* d_scores, float* ws, fc_stream stream);
-FC_API int fc_kd_loss_backward(const float* scores, const float* teacher_scores, int32_t n, float coef, float* d_scores,
-                        float* ws, fc_stream stream);
+FC_API int fc_kd_loss_backward(const float* scores, const float* teacher_scores, int32_t rows, int32_t cols, float coef,
+                        float* d_scores, float* ws, fc_stream stream);
 /* out[0] = sum_ij dKD/dteacher_scores[i,j] * teacher_scores[i,j]: what the teacher-student temperature (a factor of
- * every teacher score, teacher_student.py:68-69,157) receives through the teacher scores.  ws: 6 n floats */
-FC_API int fc_kd_teacher_scale_grad(const float* scores, const float* teacher_scores, int32_t n, float* out, float* ws,
-                             fc_stream stream);
+ * every teacher score, teacher_student.py:68-69,157) receives through the teacher scores.  ws: 3 (rows + cols) floats */
+FC_API int fc_kd_teacher_scale_grad(const float* scores, const float* teacher_scores, int32_t rows, int32_t cols,
+                             float* out, float* ws, fc_stream stream);
 /* C[N1, N2] = beta C + alpha sum_m A[m, N1] B[m, N2], exact fp32 (weight gradients dW = dY^T X; and dV = dS T,
  * dT = dS^T V of the similarity, video_text_module.py:63).  scratch >= fc_gemm_tn_scratch_bytes, 256-byte aligned. */
 FC_API size_t fc_gemm_tn_scratch_bytes(int32_t M, int32_t N1, int32_t N2);

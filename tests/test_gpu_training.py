@@ -111,10 +111,30 @@ def test_loss_backward_matches_autograd(n, scale):
     assert _rel(ds, 0.25 * x.grad) < 2e-5
     x, y = s.double().requires_grad_(True), t.double().requires_grad_(True)
     O.teacher_student_nce_loss(x, y).backward()
-    _lib.check(lib.fc_kd_loss_backward(sd.data_ptr(), td.data_ptr(), n, 3.0, ds.data_ptr(), ws.data_ptr(), _stream()))
+    _lib.check(lib.fc_kd_loss_backward(sd.data_ptr(), td.data_ptr(), n, n, 3.0, ds.data_ptr(), ws.data_ptr(), _stream()))
     assert _rel(ds, 3.0 * x.grad) < 2e-5
     out = torch.empty(1, device=DEV)
-    _lib.check(lib.fc_kd_teacher_scale_grad(sd.data_ptr(), td.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _stream()))
+    _lib.check(lib.fc_kd_teacher_scale_grad(sd.data_ptr(), td.data_ptr(), n, n, out.data_ptr(), ws.data_ptr(), _stream()))
+    assert abs(float(out) - float((y.grad * t.double()).sum())) < 1e-4 * max(1.0, float((y.grad * t.double()).abs().sum()))
+
+
+@pytest.mark.parametrize("rows,cols", [(12, 5), (5, 12), (64, 300)])
+def test_rectangular_kd_loss_and_backward(rows, cols):
+    """The videos x prompts variant (teacher_student.py:111-138): KD on [rows, cols] score matrices, where each
+    direction's "batchmean" divides by its own number of lines (F.kl_div(input) / input.size(0), loss.py:29-39)."""
+    g = torch.Generator().manual_seed(rows * cols)
+    s, t = torch.randn(rows, cols, generator=g) * 5, torch.randn(rows, cols, generator=g) * 5
+    x, y = s.double().requires_grad_(True), t.double().requires_grad_(True)
+    ref = O.teacher_student_nce_loss(x, y)
+    ref.backward()
+    sd, td = s.to(DEV), t.to(DEV)
+    assert abs(float(ops.teacher_student_nce_loss(sd, td)) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    lib = _lib.load()
+    ds, ws = torch.empty_like(sd), torch.empty(3 * (rows + cols), device=DEV)
+    _lib.check(lib.fc_kd_loss_backward(sd.data_ptr(), td.data_ptr(), rows, cols, 2.0, ds.data_ptr(), ws.data_ptr(), _stream()))
+    assert _rel(ds, 2.0 * x.grad) < 2e-5
+    out = torch.empty(1, device=DEV)
+    _lib.check(lib.fc_kd_teacher_scale_grad(sd.data_ptr(), td.data_ptr(), rows, cols, out.data_ptr(), ws.data_ptr(), _stream()))
     assert abs(float(out) - float((y.grad * t.double()).sum())) < 1e-4 * max(1.0, float((y.grad * t.double()).abs().sum()))
 
 
@@ -378,3 +398,39 @@ def test_two_rank_training_step_equals_single_rank(tmp_path):
         assert _rel(gb[sl], ga[sl]) < 2e-4, name
         off += -(-cnt // 64) * 64
     assert np.allclose(a["scale_grads"], b["scale_grads"], rtol=1e-4, atol=1e-7)
+
+
+def test_prompts_variant_of_the_distillation_step(tiny_state_dict):
+    """`prompts` (teacher_student.py:79-91,111-138): the unlabeled videos are scored against a fixed prompt list instead
+    of their own captions - the student encodes labeled captions + prompts, the unlabeled score matrix is
+    [videos x prompts].  Loss and every parameter gradient vs autograd through the oracle."""
+    d = synth.TINY
+    student_np = synth.perturbed_state_dict(tiny_state_dict, d, seed=5, rel=0.3)
+    n, f, n_lab, temp = 9, 2, 4, 0.05
+    prompts = ["a video of a cat", "someone cooking", "people dancing outdoors"]
+    video = torch.from_numpy(synth.make_video(n, f, d, seed=12))
+    ids = torch.from_numpy(synth.make_text(n, d, seed=12))
+    module = _trainer(student_np, tiny_state_dict, temp, prompts=prompts)
+    prompt_ids = module.tokenized_prompts
+    assert prompt_ids.shape == (3, d.context_length)
+    share = {"labeled": 0.5, "unlabeled": 0.5}
+    # oracle: labeled captions + prompts through the text tower, all videos through the visual tower
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch(student_np).items()}
+    ls = torch.tensor([-math.log(temp)], dtype=torch.float32, requires_grad=True)
+    ts = torch.tensor([-math.log(temp)], dtype=torch.float32, requires_grad=True)
+    text_ids = torch.cat([ids[:n_lab], prompt_ids])
+    with torch.no_grad():
+        t_sd = O.to_torch(tiny_state_dict)
+        tv, tt = O.encode_video(t_sd, video), O.encode_text(t_sd, {"input_ids": text_ids})
+    ev, et = O.encode_video(sd, video), O.encode_text(sd, {"input_ids": text_ids})
+    loss, parts = O.teacher_student_training_loss(
+        {"labeled": (ev[:n_lab], et[:n_lab]), "unlabeled": (ev[n_lab:], et[n_lab:])},
+        {"labeled": (tv[:n_lab], tt[:n_lab]), "unlabeled": (tv[n_lab:], tt[n_lab:])}, ls, ts, share)
+    loss.backward()
+    got = module.training_step_end(module.training_step(_batch(video, ids, n_lab)))
+    assert abs(got - float(loss)) < 1e-4 * abs(float(loss))
+    module.backward()
+    for k, p in module.encoder.model.named_parameters():
+        assert _rel(p.grad, sd[k].grad) < GRAD_TOL, k
+    assert abs(float(module.scale_grads[0]) - float(ls.grad)) < 1e-4 * abs(float(ls.grad))
+    assert abs(float(module.scale_grads[1]) - float(ts.grad)) < 1e-4 * abs(float(ts.grad))
