@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) quickgelu_kernel(const T* __restrict__ in
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 v = ld4<T>(in + i * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + expf(-1.702f * v[e]));  // slip.py:359-361, as the GEMM epilogue
+    for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f32(v[e]);  // slip.py:359-361; the same function as the GEMM epilogue
     st4<T>(out + i * 4, v);
   }
 }

@@ -57,12 +57,8 @@ __device__ __forceinline__ f32x4 quick_gelu_fast4(f32x4 x) {
   rh = hi * rh;
   return f32x4{rl[0], rl[1], rh[0], rh[1]};
 }
-__device__ __forceinline__ float quick_gelu_exact(float x) { return x / (1.f + expf(-1.702f * x)); }
-// d/dx [x * sigmoid(1.702 x)] = s * (1 + 1.702 x (1 - s)),  s = sigmoid(1.702 x)   (slip.py:359-361 differentiated)
-__device__ __forceinline__ float quick_gelu_grad(float x) {
-  const float s = 1.f / (1.f + expf(-1.702f * x));
-  return s * (1.f + 1.702f * x * (1.f - s));
-}
+__device__ __forceinline__ float quick_gelu_exact(float x) { return quick_gelu_f32(x); }      // common.h
+__device__ __forceinline__ float quick_gelu_grad(float x) { return quick_gelu_grad_f32(x); }
 template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
