@@ -22,8 +22,17 @@ export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
 # (fp32 runs 1024 frames per pass, bf16 512: M = frames x 197)
-if [ "$prec" = fp32 ]; then kern="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,"; minus=4000; steps=3; chunk=1024; else kern="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E"; minus=250; steps=5; chunk=512; fi
-rows=$((chunk * 197))
+# c_fc (+QuickGELU) has its own instantiation; c_proj shares the bias instantiation with QKV / out_proj and is told
+# apart by its duration window (fp32 @ 1024 frames: c_proj 7.1 ms, QKV 5.2, out_proj 1.9; bf16 @ 512: 0.40 / 0.32 / 0.12)
+if [ "$prec" = fp32 ]; then
+  steps=3; chunk=1024; rows=$((chunk * 197))
+  spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|4000|1e9|$rows|3072|768|bias_quickgelu"
+  spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 0,|6200|1e9|$rows|768|3072|bias"
+else
+  steps=5; chunk=512; rows=$((chunk * 197))
+  spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
+  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi0E|365|1e9|$rows|768|3072|bias"
+fi
 common="--precision $prec --no-bf16-mode --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup 2 $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
 echo "trace pass done"
@@ -36,13 +45,13 @@ echo "sq pass done"
 cd "$repo"
 find "$out/prof_trace_$prec" -name "*kernel_stats.csv" -exec cp {} "$keep/${tag}_bench_${prec}_kernel_stats.csv" \;
 trace=$(find "$out/prof_trace_$prec" -name "*kernel_trace.csv" | head -1)
-python3 tools/trace_summary.py "$trace" $chunk > "$keep/${tag}_bench_${prec}_trace_summary.txt"
+python3 tools/trace_summary.py "$trace" $chunk $prec > "$keep/${tag}_bench_${prec}_trace_summary.txt"
 cp "$out/prof_trace_$prec.json" "$keep/${tag}_bench_${prec}_under_rocprof.json"
 f=$(find "$out/prof_fetch_$prec" -name "*counter_collection.csv" | head -1)
 w=$(find "$out/prof_write_$prec" -name "*counter_collection.csv" | head -1)
 q=$(find "$out/prof_sq_$prec" -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py --fetch "$f" --write "$w" ${q:+--sq "$q"} --kernel "$kern" \
-  --min-us $minus --shape $rows 3072 768 --precision $prec --epilogue bias_quickgelu --out "$keep/traffic_${tag}_${prec}.json"
+python3 tools/pmc_traffic.py --fetch "$f" --write "$w" ${q:+--sq "$q"} --spec "$spec_fc" --spec "$spec_proj" \
+  --precision $prec --out "$keep/traffic_${tag}_${prec}.json"
 cp "$keep"/* profiles/
 # the raw traces are large: keep only the summaries for the trip back
 rm -rf "$out/prof_trace_$prec" "$out/prof_fetch_$prec" "$out/prof_write_$prec" "$out/prof_sq_$prec"

@@ -4,7 +4,10 @@ position in the layer sequence (QKV, out_proj | c_fc | c_proj), splits off the m
 same kernels by duration, and prints average durations / TFLOP/s per shape plus the dispatch gaps (wall span of the
 trace minus the summed kernel time).
 
-    python tools/trace_summary.py <..._kernel_trace.csv> [frames_per_chunk]
+    python tools/trace_summary.py <..._kernel_trace.csv> [frames_per_chunk] [fp32|bf16]
+
+With a precision given, launches of the OTHER precision (bench.py plants the retrieval task with an fp32 model before a
+bf16 run) are summed under "setup (other precision)" and otherwise ignored.
 """
 import csv
 import re
@@ -16,15 +19,22 @@ from collections import defaultdict
 def main():
     path = sys.argv[1]
     chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    want = sys.argv[3] if len(sys.argv) > 3 else None
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     M = chunk * 197
     shapes = {"qkv": (2304, 768), "out_proj": (768, 768), "c_fc": (3072, 768), "c_proj": (768, 3072)}
     labelled = []
     fp32 = False  # the exact-fp32 mode runs the same kernels ~8x longer: other duration cuts
+    setup_other = 0.0
     for r in rows:
         name = r["Kernel_Name"]
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        is_f32 = "<float" in name or "kernelIf" in name or "_f32_" in name or ", float>" in name
+        is_b16 = "DF16b" in name or "__bf16" in name or "attn_bf16" in name
+        if want and ((want == "bf16" and is_f32 and "fc::" in name) or (want == "fp32" and is_b16)):
+            setup_other += dur
+            continue
         if "gemm_pipelined_kernelIf" in name or "gemm_pipelined_kernel<float" in name:
             fp32 = True
         # rocprofv3 prints mangled or demangled names depending on its version: accept both spellings
@@ -65,8 +75,10 @@ def main():
         agg[label].append(dur)
     total = sum(d for _, d in labelled)
     span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3
-    print(f"total kernel time {total / 1e3:.2f} ms over {len(rows)} dispatches; trace span {span / 1e3:.2f} ms "
+    print(f"total kernel time {total / 1e3:.2f} ms over {len(labelled)} dispatches; trace span {span / 1e3:.2f} ms "
           f"(includes host-side setup between steps)")
+    if setup_other:
+        print(f"setup (other precision) {setup_other / 1e3:.2f} ms, not in the table")
     for k, durs in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         us, n = sum(durs), len(durs)
         extra = ""
