@@ -93,7 +93,7 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const f32x4& v
 }
 
 // ABL (tools/gemm_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 2 = every block stages tile (0,0);
-// 3 = no epilogue stores.
+// 3 = no epilogue stores; 4 = (f32, pipelined) write-back instead of non-temporal epilogue stores.
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   constexpr int NW = WM * WN;
@@ -673,8 +673,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
                 for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(pre[e]);
               }
             }
-            if (interior || (m < g.M && n < g.N))
-              __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<T*>(g.C) + (size_t)m * g.ldc + n));
+            if (interior || (m < g.M && n < g.N)) {
+              f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<T*>(g.C) + (size_t)m * g.ldc + n);
+              if constexpr (ABL == 4) *dst = v;  // lab: write-back stores (L2 may merge the two 64-byte halves of a line)
+              else __builtin_nontemporal_store(v, dst);
+            }
           }
         }
       }

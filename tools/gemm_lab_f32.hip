@@ -61,10 +61,12 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     if (sh.epi == 1) {
       vs = {{"sched8 (in use)", launch<1, 0, 8>}, {"sched2", launch<1, 0, 2>}, {"sched0 burst", launch<1, 0, 0>},
-            {"sched8 ABL1 no-loads", launch<1, 1, 8>}, {"sched8 ABL3 no-stores", launch<1, 3, 8>}, {"sched8 again", launch<1, 0, 8>}};
+            {"sched8 ABL1 no-loads", launch<1, 1, 8>}, {"sched8 ABL3 no-stores", launch<1, 3, 8>}, {"sched8 ABL4 plain stores", launch<1, 4, 8>},
+            {"sched8 again", launch<1, 0, 8>}};
     } else {
       vs = {{"sched2 (in use)", launch<0, 0, 2>}, {"sched8", launch<0, 0, 8>}, {"sched0 burst", launch<0, 0, 0>},
-            {"sched2 ABL1 no-loads", launch<0, 1, 2>}, {"sched2 ABL3 no-stores", launch<0, 3, 2>}, {"sched2 again", launch<0, 0, 2>}};
+            {"sched2 ABL1 no-loads", launch<0, 1, 2>}, {"sched2 ABL3 no-stores", launch<0, 3, 2>}, {"sched2 ABL4 plain stores", launch<0, 4, 2>},
+            {"sched2 again", launch<0, 0, 2>}};
     }
     for (auto& v : vs) {
       v.fn(a, st);
