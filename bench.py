@@ -356,7 +356,9 @@ def main() -> None:
         if world > 1:
             dist.destroy_process_group()
         return
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local_rank
+    # one rank per GPU; modulo the visible devices, so that a launcher that shows each rank only its own GPU (index 0)
+    # and the single-GPU gloo rehearsal (every rank on device 0) both work
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:

@@ -113,9 +113,9 @@ def evaluate(cfg: Mapping[str, Any]) -> Dict[str, float]:
 
 def _device(cfg: Mapping[str, Any]) -> torch.device:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if cfg.get("backend") == "gloo":  # rehearsal: every rank on the one GPU that is there
-        local_rank %= max(1, torch.cuda.device_count())
-    return torch.device("cuda", local_rank)
+    # modulo the visible devices: the single-GPU gloo rehearsal (every rank on device 0), and launchers that show each
+    # rank only its own GPU
+    return torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
 
 
 def _self_launch(argv) -> int:
