@@ -37,7 +37,7 @@ int num_cus() {
 template <typename T, int EPI, int SCHED>
 int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
-  constexpr int lds = 2 * (BM + BN) * ROWB + (sizeof(T) == 2 ? WM * WN * 32 * (BN / WN) : 0) + 2048;
+  constexpr int lds = 2 * (BM + BN) * ROWB + WM * WN * 2048 + 2048;  // two stages + a 2 KiB output patch per wave + bias
   auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, 0, 1, SCHED>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);

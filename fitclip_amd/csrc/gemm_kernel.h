@@ -354,9 +354,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int RPI = 64 / CPR;                       // output rows per store instruction (8 x 128 B or 4 x 256 B)
   constexpr int IPP = 16 / RPI;                       // store instructions per pass
   constexpr int OFF_STG = 2 * STAGE;                  // NW patches
-  constexpr int OFF_BIAS = OFF_STG + (kStaged ? NW * PATCH : 0);  // 2 x 1 KiB
+  constexpr int OFF_BIAS = OFF_STG + NW * 2048;       // 2 x 1 KiB   (f32 outputs: a 16-row x 128-byte patch per wave as well)
   constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
+  static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
   static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && !kStaged), "epilogue");
   static_assert(LPW + NST < 64, "vmcnt range");
   using FragT = typename Frag<T>::type;
@@ -653,30 +654,47 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           }
         }
       } else {
+        // f32 outputs: a lane holds 4 floats of ONE row per 16x16 fragment, so a direct store instruction would write
+        // 16 rows x 64 bytes (half lines; WRITE_SIZE counted 1.43x the bytes).  Two column-adjacent fragments go through
+        // a private 16-row x 128-byte LDS patch (chunk ^ (row & 7) swizzle: conflict-free both ways) and leave as
+        // 8 rows x 128 contiguous bytes per store instruction - the same number of store instructions (FM * FN).
+        char* stg = smem + OFF_STG + wave * 2048;
+        const int rrow = lane >> 3, rch = lane & 7;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int m = cm0 + wm * TM + i * 16 + r;
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            const int n = cn0 + wn * TN + j * 16 + 4 * q;
-            f32x4 v = acc[i][j];
-            if constexpr (EPI == EPI_GELU_T) {
+          for (int jj = 0; jj < FN / 2; ++jj) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
-            }
-            if constexpr (EPI == EPI_DGELU_T) {
-              // (these loads make hipcc drain vmcnt before the stores; the counted wait of the next tile stays valid,
-              // it only asks for "at most NST operations still in flight")
-              if (interior || (m < g.M && n < g.N)) {
-                const f32x4 pre = load4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)m * g.ldc + n);
+            for (int jh = 0; jh < 2; ++jh) {
+              const int j = 2 * jj + jh;
+              const int n = cn0 + wn * TN + j * 16 + 4 * q;
+              f32x4 v = acc[i][j];
+              if constexpr (EPI == EPI_GELU_T) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(pre[e]);
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
               }
+              if constexpr (EPI == EPI_DGELU_T) {
+                // (these loads make hipcc drain vmcnt before the stores; the counted wait of the next tile stays valid,
+                // it only asks for "at most NST operations still in flight")
+                if (interior || (m < g.M && n < g.N)) {
+                  const f32x4 pre = load4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)m * g.ldc + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(pre[e]);
+                }
+              }
+              *reinterpret_cast<f32x4*>(stg + r * 128 + (((jh * 4 + q) ^ (r & 7)) << 4)) = v;
             }
-            if (interior || (m < g.M && n < g.N)) {
-              f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<T*>(g.C) + (size_t)m * g.ldc + n);
-              if constexpr (ABL == 4) *dst = v;  // lab: write-back stores (L2 may merge the two 64-byte halves of a line)
-              else __builtin_nontemporal_store(v, dst);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int row = h * 8 + rrow;
+              const f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+              const int mo = cm0 + wm * TM + i * 16 + row, no = cn0 + wn * TN + jj * 32 + rch * 4;
+              if (interior || (mo < g.M && no < g.N)) {
+                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<T*>(g.C) + (size_t)mo * g.ldc + no);
+                if constexpr (ABL == 4) *dst = val;  // lab: write-back instead of non-temporal stores
+                else __builtin_nontemporal_store(val, dst);
+              }
             }
           }
         }

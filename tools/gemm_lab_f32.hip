@@ -34,7 +34,7 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
 template <int EPI, int ABL, int SCHED>
 void launch(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = 256, BN = 256;
-  constexpr int lds = 2 * (BM + BN) * ROWB + 2048;
+  constexpr int lds = 2 * (BM + BN) * ROWB + 8 * 2048 + 2048;
   auto kern = gemm_pipelined_kernel<float, BM, BN, 2, 4, EPI, ABL, 1, SCHED>;
   HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
