@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(NW * 64) attn_f32_mfma_kernel(const float* __r
   for (int t = 0; t < NKT; ++t) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float p = expf(sT[t][e] - mx);
+      const float p = exp_neg_f32(sT[t][e] - mx);  // common.h: compensated v_exp_f32, exact-fp32 grade
       sT[t][e] = p;
       sum += p;
     }

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_f32_kernel(const float* __re
     for (int t = 0; t < NKT; ++t) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = expf(sT[t][e] - mx);
+        const float p = exp_neg_f32(sT[t][e] - mx);  // the forward's function: identical P
         sT[t][e] = p;
         sum += p;
       }
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_f32_kernel(const float* __re
       for (int e = 0; e < 4; ++e) {
         const int q = t * 16 + 4 * g + e;
         const bool ok = q < S && key < S && (!CAUSAL || key <= q);
-        p[e] = ok ? expf(s[e] * 0.125f - m4[e]) * l4[e] : 0.f;
+        p[e] = ok ? exp_neg_f32(s[e] * 0.125f - m4[e]) * l4[e] : 0.f;
         ds[e] = ok ? p[e] * (dp[e] - d4[e]) : 0.f;
       }
       // dV^T[d][key] += sum_q dO[q][d] P[q][key];   dK^T[d][key] += sum_q Q[q][d] dS[q][key]

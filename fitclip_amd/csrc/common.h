@@ -147,6 +147,19 @@ int launch_token_scatter_add(const int64_t* ids, const float* g, float* dtok, in
                              hipStream_t st);
 int launch_fill_cls(float* x, const float* cls, const float* pos0, int n_seq, int S, int D, hipStream_t st);
 
+// exp(x) for x <= 0 (softmax terms) in fp32: 2^(x log2 e) on v_exp_f32 (1 ulp) with the product's rounding error and the low
+// half of log2 e carried along: 2^(t + r) = 2^t (1 + r ln 2).  1.2e-7 max relative error against float64 over [-80, 0]
+// (a plain exp2f(x * log2e) has 3.7e-6); arguments below -80 (incl. the -inf of masked keys) give exactly 0.
+__device__ __forceinline__ float exp_neg_f32(float x) {
+  constexpr float kHi = 1.4426950216293335f, kLo = 1.925963033500011e-08f;  // hi + lo = log2(e)
+  const float xs = fmaxf(x, -80.f);
+  const float t = xs * kHi;
+  const float r = __builtin_fmaf(xs, kHi, -t) + xs * kLo;
+  float e = __builtin_amdgcn_exp2f(t);
+  e = __builtin_fmaf(e, r * 0.6931471805599453f, e);
+  return x > -80.f ? e : 0.f;
+}
+
 // QuickGELU in fp32 (slip.py:359-361): x * sigmoid(1.702 x) = x / (1 + 2^t), t = -(1.702 log2 e) x.
 // v_exp_f32 / v_rcp_f32 are 1-ulp instructions; what would cost accuracy is the rounding of the product t (|t| up to ~40),
 // so t carries its exact fma residual and the low half of the constant: 2^(t + r) = 2^t (1 + r ln 2).  1.9e-7 max relative
