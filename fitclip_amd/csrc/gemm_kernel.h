@@ -359,7 +359,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
   static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && !kStaged), "epilogue");
-  static_assert(LPW + NST < 64, "vmcnt range");
+  // the counted wait behind the epilogue stores needs LPW + NST to fit the 6-bit vmcnt; tilings with more stores per wave
+  // (4 waves of 128x128) wait for everything at the first hand-over of the next tile instead
+  constexpr bool kCounted = LPW + NST < 64;
   using FragT = typename Frag<T>::type;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -547,7 +549,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           // and the first fragment reads of the next K-tile are covered by MFMAs.  Every LDS read of this stage has
           // been issued; once they have returned the stage may be overwritten by the other waves' DMA.
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (kt == 0 && prev_counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
+          if constexpr (kCounted) {
+            if (kt == 0 && prev_counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
+          } else {
+            wait_vmcnt<0>();
+          }
           block_barrier();
           if (ABL != 1) {
             if (kt + 2 < nk) {

@@ -31,14 +31,14 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
   }
 }
 
-template <int EPI, int ABL, int SCHED>
+template <int EPI, int ABL, int SCHED, int WM = 2, int WN = 4>
 void launch(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = 256, BN = 256;
-  constexpr int lds = 2 * (BM + BN) * ROWB + 8 * 2048 + 2048;
-  auto kern = gemm_pipelined_kernel<float, BM, BN, 2, 4, EPI, ABL, 1, SCHED>;
+  constexpr int lds = 2 * (BM + BN) * ROWB + WM * WN * 2048 + 2048;
+  auto kern = gemm_pipelined_kernel<float, BM, BN, WM, WN, EPI, ABL, 1, SCHED>;
   HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, 256)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(std::min(tiles, 256)), dim3(WM * WN * 64), lds, st, a);
 }
 
 struct Variant { const char* name; void (*fn)(const GemmArgs&, hipStream_t); };
@@ -62,11 +62,11 @@ int main(int argc, char** argv) {
     if (sh.epi == 1) {
       vs = {{"sched8 (in use)", launch<1, 0, 8>}, {"sched2", launch<1, 0, 2>}, {"sched0 burst", launch<1, 0, 0>},
             {"sched8 ABL1 no-loads", launch<1, 1, 8>}, {"sched8 ABL3 no-stores", launch<1, 3, 8>}, {"sched8 ABL4 plain stores", launch<1, 4, 8>},
-            {"sched8 again", launch<1, 0, 8>}};
+            {"4 waves 128x128 sched0", launch<1, 0, 0, 2, 2>}, {"sched8 again", launch<1, 0, 8>}};
     } else {
       vs = {{"sched2 (in use)", launch<0, 0, 2>}, {"sched8", launch<0, 0, 8>}, {"sched0 burst", launch<0, 0, 0>},
             {"sched2 ABL1 no-loads", launch<0, 1, 2>}, {"sched2 ABL3 no-stores", launch<0, 3, 2>}, {"sched2 ABL4 plain stores", launch<0, 4, 2>},
-            {"sched2 again", launch<0, 0, 2>}};
+            {"4 waves 128x128 sched0", launch<0, 0, 0, 2, 2>}, {"sched2 again", launch<0, 0, 2>}};
     }
     for (auto& v : vs) {
       v.fn(a, st);
