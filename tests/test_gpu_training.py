@@ -434,3 +434,25 @@ def test_prompts_variant_of_the_distillation_step(tiny_state_dict):
         assert _rel(p.grad, sd[k].grad) < GRAD_TOL, k
     assert abs(float(module.scale_grads[0]) - float(ls.grad)) < 1e-4 * abs(float(ls.grad))
     assert abs(float(module.scale_grads[1]) - float(ts.grad)) < 1e-4 * abs(float(ts.grad))
+
+
+def test_micro_batched_forward_backward_accumulates(tiny_state_dict):
+    """A local batch larger than `max_frames_per_pass` / `max_texts_per_pass` goes through the towers in several passes
+    (one activation arena each) and the backward ACCUMULATES the parameter gradients over the passes: same embeddings
+    bit for bit, same gradients up to summation order."""
+    d = synth.TINY
+    student_np = synth.perturbed_state_dict(tiny_state_dict, d, seed=5, rel=0.3)
+    n, f, n_lab = 8, 2, 4
+    video = torch.from_numpy(synth.make_video(n, f, d, seed=9))
+    ids = torch.from_numpy(synth.make_text(n, d, seed=9))
+    whole = _trainer(student_np, tiny_state_dict, 0.05)
+    parts = _trainer(student_np, tiny_state_dict, 0.05, max_frames_per_pass=6, max_texts_per_pass=3)
+    outs = []
+    for module in (whole, parts):
+        out = module.training_step(_batch(video, ids, n_lab))
+        outs.append(torch.cat([out["labeled"][0][0], out["unlabeled"][0][0], out["labeled"][0][1], out["unlabeled"][0][1]]))
+        module.training_step_end(out)
+        module.backward()
+    assert torch.equal(outs[0], outs[1])
+    for (k, a), (_, b) in zip(whole.encoder.model.named_parameters(), parts.encoder.model.named_parameters()):
+        assert _rel(b.grad, a.grad.cpu()) < 1e-5, k
