@@ -1,4 +1,6 @@
 """`python -m fitclip_amd command=evaluate encoder=clip_vit_b_16 data=synthetic ...`
+`python -m fitclip_amd command=train encoder=teacher_student_vit_b_16 steps=10 n_labeled=8 n_unlabeled=8 ...`
+`python -m fitclip_amd command=predict encoder=clip_vit_b_16 n_clips=64 output_path=predictions.pt`
 
 The `command=evaluate` path of the reference CLI (`aligner/__main__.py:27-69`, `aligner/cli.py:81-150`) without Hydra /
 Lightning: `key=value` overrides, `_target_` instantiation of the encoder config group, seed 42
@@ -35,6 +37,8 @@ DEFAULTS: Dict[str, Any] = {
     "command": "evaluate", "encoder": "clip_vit_b_16", "data": "synthetic", "seed": 42, "n_clips": 64,
     "num_frames": 4, "eval_batch_size": 32, "init_temperature": 0.015, "precision": None, "weight_for_2": None,
     "gpus": 1, "backend": "nccl", "bpe_path": None,
+    # command=train (config/teacher_student_trainer.yaml + config/data/mixed_batch_*.yaml): per-rank batch composition
+    "steps": 10, "n_labeled": 8, "n_unlabeled": 8, "lr": 3e-6, "fit_temperature": False, "output_path": "predictions.pt",
 }
 
 
@@ -111,6 +115,59 @@ def evaluate(cfg: Mapping[str, Any]) -> Dict[str, float]:
         return module.validation_epoch_end()
 
 
+def train(cfg: Mapping[str, Any]) -> Dict[str, Any]:
+    """`command=train` with `encoder=teacher_student_*`: the distillation loop of the reference
+    (config/teacher_student_trainer.yaml -> TeacherStudentLightningModule; optimiser torch.optim.AdamW lr 3e-6,
+    config/trainer.yaml:21-23; temperatures init 0.015, fit_temperature false, :17-20) over synthetic mixed batches
+    (`n_labeled` + `n_unlabeled` clips per rank and step, as config/data/mixed_batch_*.yaml composes them)."""
+    from .training import TeacherStudentTrainer
+    rank, world = D.world()
+    device = _device(cfg)
+    torch.cuda.set_device(device)
+    torch.manual_seed(cfg["seed"])
+    node = load_encoder_config(cfg["encoder"], {**cfg, "precision": None}, device)
+    if not (isinstance(node, dict) and {"teacher", "student"} <= set(node)):
+        raise SystemExit("command=train needs an encoder config with `teacher` and `student` (e.g. teacher_student_vit_b_16)")
+    teacher, student = instantiate(node["teacher"]).to(device), instantiate(node["student"]).to(device)
+    module = TeacherStudentTrainer(student, teacher, init_temperature=cfg["init_temperature"], lr=cfg["lr"],
+                                   fit_temperature=bool(cfg["fit_temperature"]))
+    dims = student.model.dims
+    per = cfg["n_labeled"] + cfg["n_unlabeled"]
+    names = ["labeled"] * cfg["n_labeled"] + ["unlabeled"] * cfg["n_unlabeled"]
+    losses = []
+    for step in range(cfg["steps"]):
+        first = (step * world + rank) * per
+        video = torch.from_numpy(synth.make_video(per, cfg["num_frames"], dims, cfg["seed"], first)).to(device)
+        ids = torch.from_numpy(synth.make_text(per, dims, cfg["seed"], first)).to(device)
+        losses.append(module.fit_step({"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
+                                       "text_teacher": {"input_ids": ids}, "dataset": names}))
+    return {"steps": cfg["steps"], "clips_per_step": per * world, "loss/train": losses,
+            "loss/train_labeled": module.last_losses.get("labeled"), "loss/train_unlabeled": module.last_losses.get("unlabeled"),
+            "temperature/labeled": 1 / __import__("math").exp(module.logit_scale)}
+
+
+def predict(cfg: Mapping[str, Any]) -> Dict[str, Any]:
+    """`command=predict` (aligner/__main__.py:70-90): encodes every clip / caption and saves {"encoded_videos",
+    "encoded_texts", "video_ids"} (the `predict_step` mapping, video_text_module.py:84-92) to `output_path`."""
+    from .retrieval import VideoTextModule
+    device = _device(cfg)
+    torch.cuda.set_device(device)
+    encoder = instantiate(load_encoder_config(cfg["encoder"], cfg, device)).to(device)
+    module, dims, bs = VideoTextModule(encoder, init_temperature=cfg["init_temperature"]), encoder.model.dims, cfg["eval_batch_size"]
+    outs = []
+    with torch.inference_mode():
+        for s in range(0, cfg["n_clips"], bs):
+            e = min(cfg["n_clips"], s + bs)
+            outs.append(module.predict_step({
+                "video": torch.from_numpy(synth.make_video(e - s, cfg["num_frames"], dims, cfg["seed"], s)).to(device),
+                "text": {"input_ids": torch.from_numpy(synth.make_text(e - s, dims, cfg["seed"], s)).to(device)},
+                "video_id": [f"clip{i}" for i in range(s, e)]}))
+    merged = {k: torch.cat([o[k] for o in outs]).cpu() if isinstance(outs[0][k], torch.Tensor)
+              else [x for o in outs for x in o[k]] for k in outs[0]}
+    torch.save(merged, cfg["output_path"])
+    return {"output_path": cfg["output_path"], "n": len(merged["video_ids"])}
+
+
 def _device(cfg: Mapping[str, Any]) -> torch.device:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # modulo the visible devices: the single-GPU gloo rehearsal (every rank on device 0), and launchers that show each
@@ -133,8 +190,8 @@ def _self_launch(argv) -> int:
 def main(argv=None) -> None:
     argv = sys.argv[1:] if argv is None else list(argv)
     cfg = parse_overrides(argv)
-    if cfg["command"] not in ("evaluate", "validate"):
-        raise SystemExit("only command=evaluate (alias validate) is implemented: the inference path of the reference")
+    if cfg["command"] not in ("evaluate", "validate", "train", "predict"):
+        raise SystemExit("commands: evaluate (alias validate), predict, train (tune / test are Lightning plumbing)")
     if cfg["gpus"] > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_self_launch(argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,7 +203,7 @@ def main(argv=None) -> None:
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(cfg["backend"])
-    metrics = evaluate(cfg)
+    metrics = {"train": train, "predict": predict}.get(cfg["command"], evaluate)(cfg)
     if D.world()[0] == 0:
         print(json.dumps({"command": cfg["command"], "encoder": cfg["encoder"], "n_clips": cfg["n_clips"],
                           "num_frames": cfg["num_frames"], **metrics}))

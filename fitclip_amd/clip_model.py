@@ -302,15 +302,17 @@ def load_clip_model(name: str, precision: str = "bf16", device: Optional[Union[s
     """Counterpart of `load_clip_model` (clip_video_text_encoder.py:30-61) for LOCAL checkpoints.
 
     `name` is a path to a bare OpenAI-CLIP-named state dict (what `scripts/checkpoint_to_state_dict.py` of the
-    reference writes), with or without `logit_scale`; or `synthetic:<seed>` / `synthetic-student:<seed>` for seeded ViT-B/16 weights.  Model names
+    reference writes), with or without `logit_scale`; or `synthetic:<seed>` / `synthetic-student:<seed>` for seeded ViT-B/16 weights (`synthetic-tiny[-student]:<seed>`: the miniature of the tests).  Model names
     and URLs ("ViT-B/16", "https://...") need a network fetch and are rejected: there is no egress here.
     """
     if name.startswith("synthetic"):
         from . import synth
         seed = int(name.split(":", 1)[1]) if ":" in name else 42
-        sd = synth.make_state_dict(VIT_B_16, seed=seed)
-        if name.startswith("synthetic-student"):  # a perturbed copy: the "fine-tuned" model2 of a WiSE ensemble
-            sd = synth.perturbed_state_dict(sd, VIT_B_16, seed=seed + 1, rel=0.05)
+        kind = name.split(":", 1)[0]
+        dims = synth.TINY if "-tiny" in kind else VIT_B_16  # `synthetic-tiny[-student]`: the miniature of the tests
+        sd = synth.make_state_dict(dims, seed=seed)
+        if kind.endswith("-student"):  # a perturbed copy: the "fine-tuned" model2 of a WiSE ensemble / the KD student
+            sd = synth.perturbed_state_dict(sd, dims, seed=seed + 1, rel=0.3 if dims is synth.TINY else 0.05)
         return build_clip(sd, precision=precision, device=device, **kwargs)
     if "://" in name or not os.path.exists(name):
         raise FileNotFoundError(f"{name!r}: only local state-dict files or 'synthetic[:seed]' can be loaded offline")

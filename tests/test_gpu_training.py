@@ -456,3 +456,28 @@ def test_micro_batched_forward_backward_accumulates(tiny_state_dict):
     assert torch.equal(outs[0], outs[1])
     for (k, a), (_, b) in zip(whole.encoder.model.named_parameters(), parts.encoder.model.named_parameters()):
         assert _rel(b.grad, a.grad.cpu()) < 1e-5, k
+
+
+def test_train_command_reduces_the_distillation_loss(capsys):
+    """`python -m fitclip_amd command=train encoder=teacher_student_tiny`: the distillation loop end to end (student
+    forward / losses / backward / AdamW per step over synthetic mixed batches).  With a learning rate large enough to
+    matter on the miniature, the training loss of the SAME batch composition must go down."""
+    import json
+    from fitclip_amd.__main__ import main
+    main(["command=train", "encoder=teacher_student_tiny", "steps=12", "n_labeled=6", "n_unlabeled=6", "num_frames=2",
+          "lr=2e-4", "init_temperature=0.05", "seed=3"])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    losses = out["loss/train"]
+    assert len(losses) == 12 and all(np.isfinite(losses))
+    assert np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3]), losses
+
+
+def test_predict_command_writes_the_embeddings(tmp_path, capsys):
+    import json
+    from fitclip_amd.__main__ import main
+    path = str(tmp_path / "predictions.pt")
+    main(["command=predict", "encoder=clip_vit_b_16", "n_clips=5", "num_frames=1", "eval_batch_size=2", f"output_path={path}"])
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    pred = torch.load(path)
+    assert out["n"] == 5 and pred["encoded_videos"].shape == pred["encoded_texts"].shape == (5, 512)
+    assert pred["video_ids"] == [f"clip{i}" for i in range(5)]
