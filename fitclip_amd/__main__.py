@@ -51,6 +51,11 @@ def parse_overrides(argv) -> Dict[str, Any]:
         if key not in cfg:
             raise SystemExit(f"unknown option {key!r}; known: {sorted(cfg)}")
         cfg[key] = yaml.safe_load(value)
+        if isinstance(cfg[key], str):  # YAML 1.1 reads "3e-6" as a string: accept the usual float spellings
+            try:
+                cfg[key] = float(cfg[key])
+            except ValueError:
+                pass
     return cfg
 
 

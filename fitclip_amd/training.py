@@ -39,7 +39,7 @@ class StudentTrainer:
         if model.precision not in ("fp32", "f32", "float32"):
             raise ValueError("only precision='fp32' models train (the reference trains in float32)")
         self.encoder, self.model = encoder, model
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.max_frames, self.max_texts = max_frames_per_pass, max_texts_per_pass
         self.step_count = 0
         dev = model._device()
