@@ -39,6 +39,7 @@ DEFAULTS: Dict[str, Any] = {
     "gpus": 1, "backend": "nccl", "bpe_path": None,
     # command=train (config/teacher_student_trainer.yaml + config/data/mixed_batch_*.yaml): per-rank batch composition
     "steps": 10, "n_labeled": 8, "n_unlabeled": 8, "lr": 3e-6, "fit_temperature": False, "output_path": "predictions.pt",
+    "repeat_batch": False,  # train: every step sees the first batch again (overfitting smoke test)
 }
 
 
@@ -141,7 +142,7 @@ def train(cfg: Mapping[str, Any]) -> Dict[str, Any]:
     names = ["labeled"] * cfg["n_labeled"] + ["unlabeled"] * cfg["n_unlabeled"]
     losses = []
     for step in range(cfg["steps"]):
-        first = (step * world + rank) * per
+        first = ((0 if cfg["repeat_batch"] else step) * world + rank) * per
         video = torch.from_numpy(synth.make_video(per, cfg["num_frames"], dims, cfg["seed"], first)).to(device)
         ids = torch.from_numpy(synth.make_text(per, dims, cfg["seed"], first)).to(device)
         losses.append(module.fit_step({"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
