@@ -268,11 +268,48 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
   return launch_add_layernorm(s.x, xs_pool, s.xn, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 0, st);
 }
 
-int default_chunk(const fc_handle* h, int tower) {
-  // fp32: 1024 frames per pass (9456 tiles per c_fc launch = 36.9 rounds of the 256 CUs: 0.2 % tail, against 2.8 % at
-  // 512 frames; measured +1.7 % on the step).  bf16: 512 (profiles/r01: larger chunks do not pay there).
-  if (tower == 0) return h->cfg.chunk_frames > 0 ? h->cfg.chunk_frames : (h->cfg.precision == FC_PREC_F32 ? 1024 : 512);
-  return h->cfg.chunk_texts > 0 ? h->cfg.chunk_texts : 1024;
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
+// Items per pass of a tower over `n` items.  bf16: 512 frames (profiles/r01: the step does not react to the chunk size
+// there - when some CUs run out of tiles the others speed up, the chip being power- and bandwidth-limited).  fp32 is
+// MFMA-bound on every CU, so whole rounds of 256 x 256 tiles over the CUs matter: a pass whose number of 256-row panels is
+// a multiple of the CU count (ViT-B/16: 998 frames = 768 panels = 3, 9, 12 full rounds for the N = 768 / 2304 / 3072
+// GEMMs) runs its block GEMMs without a partial last round; 1024 frames would leave c_proj / out_proj at 9.23 rounds =
+// 92 %.  The pass size is chosen among those "whole round" sizes (and n itself) by the modelled number of tile rounds;
+// measured 449.6 vs 433.4 pairs/s (+3.7 %) on the 2048-frame bench step (998 + 998 + 52).
+int planned_chunk(const fc_handle* h, int tower, int n) {
+  const fc_config& c = h->cfg;
+  if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
+  if (c.chunk_frames > 0) return c.chunk_frames;
+  if (c.precision != FC_PREC_F32) return 512;
+  const long T = h->vtokens(), w = c.vision_width, cus = device_cus();
+  const long max_frames = std::max(1L, (long)((1LL << 32) - 1) / (16 * w) / T);  // 32-bit operand offsets of the 4w-wide buffer
+  auto rounds = [&](long frames) {  // tile rounds x K-steps of the four block GEMMs of one pass
+    const long panels = (frames * T + 255) / 256;
+    const long shapes[4][2] = {{3 * w, w}, {w, w}, {4 * w, w}, {w, 4 * w}};
+    long total = 0;
+    for (auto& sh : shapes) total += (panels * ((sh[0] + 255) / 256) + cus - 1) / cus * (sh[1] / 32);
+    return total;
+  };
+  auto cost = [&](long chunk) { return (n / chunk) * rounds(chunk) + (n % chunk ? rounds(n % chunk) : 0); };
+  long best = std::min<long>(n, max_frames), best_cost = cost(best);
+  for (long j = 1; j <= 16; ++j) {
+    const long cand = j * cus * 256 / T;
+    if (cand > max_frames || cand >= n) break;
+    const long cc = cost(cand);
+    if (cc < best_cost || (cc == best_cost && cand > best)) best = cand, best_cost = cc;
+  }
+  return (int)best;
 }
 
 size_t per_item_bytes(const fc_handle* h, int tower) {
@@ -400,7 +437,7 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
 
 size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n) {
   if (!h || n <= 0 || tower < 0 || tower > 1) return 0;
-  const int c = std::min(n, default_chunk(h, tower));
+  const int c = std::min(n, planned_chunk(h, tower, n));
   const fc_config& k = h->cfg;
   return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp()).total
                     : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0).total;
@@ -416,7 +453,7 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
   const fc_config& c = h->cfg;
   const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_kp();
   const size_t per = per_item_bytes(h, 0);
-  int chunk = std::min(n, default_chunk(h, 0));
+  int chunk = std::min(n, planned_chunk(h, 0, n));
   if (carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) {  // smaller workspace: as many items as fit
     chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
     while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) --chunk;
@@ -460,7 +497,7 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
   const fc_config& c = h->cfg;
   const int tw = c.transformer_width, L = c.context_length;
   const size_t per = per_item_bytes(h, 1);
-  int chunk = std::min(n, default_chunk(h, 1));
+  int chunk = std::min(n, planned_chunk(h, 1, n));
   if (carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) {
     chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
     while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) --chunk;

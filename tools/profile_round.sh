@@ -21,11 +21,11 @@ cd /tmp && export TMPDIR=/tmp
 export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
-# (fp32 runs 1024 frames per pass, bf16 512: M = frames x 197)
+# (fp32 runs 998 frames per pass = 768 panels of 256 rows = whole rounds of the 256 CUs, bf16 512: M = frames x 197)
 # c_fc (+QuickGELU) has its own instantiation; c_proj shares the bias instantiation with QKV / out_proj and is told
-# apart by its duration window (fp32 @ 1024 frames: c_proj 7.1 ms, QKV 5.2, out_proj 1.9; bf16 @ 512: 0.40 / 0.32 / 0.12)
+# apart by its duration window (fp32 @ 998 frames per pass: c_proj 6.7 ms, QKV 4.9, out_proj 1.8; bf16 @ 512: 0.40 / 0.32 / 0.12)
 if [ "$prec" = fp32 ]; then
-  steps=3; chunk=1024; rows=$((chunk * 197))
+  steps=3; chunk=998; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|4000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 0,|6200|1e9|$rows|768|3072|bias"
 else

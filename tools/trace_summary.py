@@ -62,12 +62,12 @@ def main():
     for item in labelled:
         if item[0] == "bias_gemm":
             if item[1] < cut:
-                item[0] = "text gemm"
+                item[0] = "text / short-pass gemm"
             else:
                 item[0] = ("qkv", "out_proj", "c_proj")[seq % 3]
                 seq += 1
         elif item[0] == "c_fc" and item[1] < cut:
-            item[0] = "text gemm"
+            item[0] = "text / short-pass gemm"
         elif item[0] in ("attention", "add_layernorm") and item[1] < cut_small:
             item[0] = "text " + item[0]
     agg = defaultdict(list)
