@@ -197,7 +197,7 @@ class CLIP(nn.Module):
     def _chunk_frames(self) -> int:
         if self.chunk_frames > 0:
             return self.chunk_frames
-        return 998 if _PRECISIONS[self.precision] == _lib.PREC_F32 else 512  # the library's default pass size (ViT-B/16)
+        return 998 if _PRECISIONS[self.precision] == _lib.PREC_F32 else 512  # order of the library's pass size (ViT-B/16)
 
     def _encode_image_lanes(self, rt: "_Runtime", image: torch.Tensor, out: torch.Tensor, lanes: int) -> None:
         """Large batches (>= `lanes` chunks): contiguous slices of the frames go to `lanes` HIP streams (the caller's +

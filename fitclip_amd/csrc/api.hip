@@ -286,7 +286,8 @@ int device_cus() {
 // a multiple of the CU count (ViT-B/16: 998 frames = 768 panels = 3, 9, 12 full rounds for the N = 768 / 2304 / 3072
 // GEMMs) runs its block GEMMs without a partial last round; 1024 frames would leave c_proj / out_proj at 9.23 rounds =
 // 92 %.  The pass size is chosen among those "whole round" sizes (and n itself) by the modelled number of tile rounds;
-// measured 449.6 vs 433.4 pairs/s (+3.7 %) on the 2048-frame bench step (998 + 998 + 52).
+// measured on the 2048-frame bench step: 433 pairs/s with 2 x 1024 frames, 450 with 998 + 998 + 52, 451 with the
+// planner's 1663 + 385 (1280 panels; the limit is the 32-bit operand offset of the 4w-wide buffer).
 int planned_chunk(const fc_handle* h, int tower, int n) {
   const fc_config& c = h->cfg;
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;

@@ -21,13 +21,13 @@ cd /tmp && export TMPDIR=/tmp
 export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
-# (fp32 runs 998 frames per pass = 768 panels of 256 rows = whole rounds of the 256 CUs, bf16 512: M = frames x 197)
+# (fp32: the 2048 frames of a bench step run as 1663 + 385: 1663 frames = 1280 panels of 256 rows = whole rounds of the 256 CUs; bf16 512)
 # c_fc (+QuickGELU) has its own instantiation; c_proj shares the bias instantiation with QKV / out_proj and is told
-# apart by its duration window (fp32 @ 998 frames per pass: c_proj 6.7 ms, QKV 4.9, out_proj 1.8; bf16 @ 512: 0.40 / 0.32 / 0.12)
+# apart by its duration window (fp32 @ 1663 frames in the main pass: c_proj 11.4 ms, QKV 8.2, out_proj 3.0; bf16 @ 512: 0.40 / 0.32 / 0.12)
 if [ "$prec" = fp32 ]; then
-  steps=3; chunk=998; rows=$((chunk * 197))
-  spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|4000|1e9|$rows|3072|768|bias_quickgelu"
-  spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 0,|6200|1e9|$rows|768|3072|bias"
+  steps=3; chunk=1663; rows=$((chunk * 197))
+  spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
+  spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 0,|9800|1e9|$rows|768|3072|bias"
 else
   steps=5; chunk=512; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
