@@ -33,10 +33,10 @@ int num_cus() {
   return cus;
 }
 
-// persistent, pipelined kernel: one workgroup per CU walks the tiles
-template <typename T, int EPI, int SCHED>
+// persistent, pipelined kernel: one workgroup per CU walks the tiles (BM = 256; 128 for the tail launch below)
+template <typename T, int EPI, int SCHED, int BM = 256>
 int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
+  constexpr int BN = 256, WM = 2, WN = 4;
   constexpr int lds = 2 * (BM + BN) * ROWB + WM * WN * 2048 + 2048;  // two stages + a 2 KiB output patch per wave + bias
   auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, 0, 1, SCHED>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
@@ -55,7 +55,7 @@ int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
 // between 2 and 8, out_proj and c_proj are fastest with 2.  Hence: 8 for the QuickGELU GEMM, 2 otherwise.
 // FITCLIP_GEMM_SCHED=0|2|8 overrides (A/B runs); the result does not depend on the schedule.
 template <typename T, int EPI>
-int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
+int launch_pipelined_full(const GemmArgs& a, hipStream_t stream) {
   static const int forced = [] {
     const char* e = getenv("FITCLIP_GEMM_SCHED");
     return e ? atoi(e) : -1;
@@ -66,6 +66,46 @@ int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
     case 8: return launch_pipelined_sched<T, EPI, 8>(a, stream);
     default: return launch_pipelined_sched<T, EPI, 0>(a, stream);
   }
+}
+
+// fp32 is MFMA-bound on every CU, so a partial last round of 256 x 256 tiles costs a whole round (api.hip plans the
+// passes of a big batch around that; a small batch - the reference evaluates 32 clips = 128 frames at a time - cannot be
+// planned).  Here the row panels that fill whole rounds go to one launch and the REST to a second launch of 128 x 256
+// tiles when its half-size rounds are cheaper (c_proj / out_proj of 128 frames: 297 tiles = 2 rounds -> 591 half tiles =
+// 3 half rounds; QKV of 385 frames: 11 -> 9 + 1.6 rounds).  Same K order per output element: results are bit-identical.
+template <typename T, int EPI>
+int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 4) {
+    static const bool no_tail = getenv("FITCLIP_GEMM_NO_TAIL") != nullptr;  // A/B switch
+    const int cus = num_cus(), tilesN = (a.N + 255) / 256, panels = (a.M + 255) / 256;
+    int g = cus, t = tilesN;
+    while (t) { const int r = g % t; g = t; t = r; }  // gcd
+    const int step = cus / g;                          // panels per whole number of rounds
+    const int p0 = panels / step * step;
+    const long rem_tiles = (long)(panels - p0) * tilesN;
+    if (rem_tiles > 0 && !no_tail) {
+      const int rem_rows = a.M - p0 * 256;
+      const long half_tiles = (long)((rem_rows + 127) / 128) * tilesN;
+      const double cost256 = (double)((rem_tiles + cus - 1) / cus);
+      const double cost128 = 0.54 * (double)((half_tiles + cus - 1) / cus);  // a 128-row tile: half the work at ~92 % of the rate
+      if (cost128 < cost256) {
+        if (p0 > 0) {
+          GemmArgs head = a;
+          head.M = p0 * 256;
+          const int rc = launch_pipelined_full<T, EPI>(head, stream);
+          if (rc != FC_OK) return rc;
+        }
+        GemmArgs tail = a;
+        const size_t r0 = (size_t)p0 * 256;
+        tail.M = rem_rows;
+        tail.A = static_cast<const char*>(a.A) + r0 * a.lda * sizeof(T);
+        tail.C = static_cast<char*>(a.C) + r0 * a.ldc * sizeof(T);
+        if constexpr (EPI == EPI_DGELU_T) tail.aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.aux) + r0 * a.ldc * sizeof(T));
+        return launch_pipelined_sched<T, EPI, 0, 128>(tail, stream);
+      }
+    }
+  }
+  return launch_pipelined_full<T, EPI>(a, stream);
 }
 
 template <typename T>
