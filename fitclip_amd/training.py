@@ -362,6 +362,50 @@ class TeacherStudentTrainer(TeacherStudentModule):
             self.scales[:2].clamp_(max=self.max_logit_scale)
         self.logit_scale, self.teacher_student_logit_scale = (float(x) for x in self.scales[:2].tolist())
 
+    # ------------------------------------------------------------------------------------------ checkpoint / resume
+    def checkpoint(self) -> Dict[str, Any]:
+        """A Lightning-shaped training checkpoint: `state_dict` with the keys of the reference's module (`encoder.*`,
+        `teacher.*`, the two logit scales - what `fitclip_amd.checkpoint` and the reference's scripts read),
+        `optimizer_states[0]` in `torch.optim.AdamW.state_dict()` layout (index i = the i-th encoder parameter in
+        `named_parameters()` order, then the two temperatures) and `global_step`."""
+        from .checkpoint import module_state_dict
+        s = self.student
+        state = {}
+        for i, (name, p) in enumerate(s.model._named_weights()):
+            o, n = s.offsets[name], p.numel()
+            state[i] = {"step": torch.tensor(float(s.step_count)), "exp_avg": s.exp_avg[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": s.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        n_enc = len(state)
+        for j in range(2):
+            state[n_enc + j] = {"step": torch.tensor(float(s.step_count)), "exp_avg": self.scale_m[j].clone(),
+                                "exp_avg_sq": self.scale_v[j].clone()}
+        group = {"lr": s.lr, "betas": s.betas, "eps": s.eps, "weight_decay": s.weight_decay, "amsgrad": False,
+                 "maximize": False, "params": list(range(n_enc + 2))}
+        return {"state_dict": {k: v.detach().clone() for k, v in module_state_dict(self).items()},
+                "optimizer_states": [{"state": state, "param_groups": [group]}], "global_step": s.step_count}
+
+    def load_checkpoint(self, ckpt: Mapping[str, Any]) -> None:
+        """Resumes from `checkpoint()`: weights, AdamW moments, step count and temperatures; the next `fit_step`
+        continues exactly where the saved run would have."""
+        from .checkpoint import load_module_state_dict
+        s = self.student
+        load_module_state_dict(self, ckpt["state_dict"], strict=True)     # copies into the flat parameter buffer (views)
+        self.scales[0], self.scales[1] = self.logit_scale, self.teacher_student_logit_scale
+        opt = ckpt["optimizer_states"][0]
+        named = s.model._named_weights()
+        with torch.no_grad():
+            for i, (name, p) in enumerate(named):
+                o, n = s.offsets[name], p.numel()
+                s.exp_avg[o:o + n].view(p.shape).copy_(opt["state"][i]["exp_avg"])
+                s.exp_avg_sq[o:o + n].view(p.shape).copy_(opt["state"][i]["exp_avg_sq"])
+            for j in range(2):
+                self.scale_m[j] = opt["state"][len(named) + j]["exp_avg"]
+                self.scale_v[j] = opt["state"][len(named) + j]["exp_avg_sq"]
+        s.step_count = int(ckpt["global_step"])
+        g = opt["param_groups"][0]
+        s.lr, s.betas, s.eps, s.weight_decay = float(g["lr"]), tuple(map(float, g["betas"])), float(g["eps"]), float(g["weight_decay"])
+        s.rebind()
+
     def fit_step(self, batch: Mapping[str, Any]) -> float:
         loss = self.training_step_end(self.training_step(batch))
         self.backward()
