@@ -373,15 +373,15 @@ class TeacherStudentTrainer(TeacherStudentModule):
         state = {}
         for i, (name, p) in enumerate(s.model._named_weights()):
             o, n = s.offsets[name], p.numel()
-            state[i] = {"step": torch.tensor(float(s.step_count)), "exp_avg": s.exp_avg[o:o + n].view(p.shape).clone(),
-                        "exp_avg_sq": s.exp_avg_sq[o:o + n].view(p.shape).clone()}
+            state[i] = {"step": torch.tensor(float(s.step_count)), "exp_avg": s.exp_avg[o:o + n].view(p.shape).cpu(),
+                        "exp_avg_sq": s.exp_avg_sq[o:o + n].view(p.shape).cpu()}
         n_enc = len(state)
         for j in range(2):
-            state[n_enc + j] = {"step": torch.tensor(float(s.step_count)), "exp_avg": self.scale_m[j].clone(),
-                                "exp_avg_sq": self.scale_v[j].clone()}
+            state[n_enc + j] = {"step": torch.tensor(float(s.step_count)), "exp_avg": self.scale_m[j].cpu(),
+                                "exp_avg_sq": self.scale_v[j].cpu()}
         group = {"lr": s.lr, "betas": s.betas, "eps": s.eps, "weight_decay": s.weight_decay, "amsgrad": False,
                  "maximize": False, "params": list(range(n_enc + 2))}
-        return {"state_dict": {k: v.detach().clone() for k, v in module_state_dict(self).items()},
+        return {"state_dict": {k: v.detach().cpu() for k, v in module_state_dict(self).items()},  # host tensors
                 "optimizer_states": [{"state": state, "param_groups": [group]}], "global_step": s.step_count}
 
     def load_checkpoint(self, ckpt: Mapping[str, Any]) -> None:
