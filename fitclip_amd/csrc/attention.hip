@@ -638,6 +638,161 @@ __global__ void __launch_bounds__(NW * 64) attn_f32_mfma_kernel(const float* __r
   }  // q-tile loop
 }
 
+// ---- exact-fp32 attention for 97..224 tokens (the ViT's 197), second generation.  attn_f32_mfma_kernel keeps K and V of a
+// whole (sequence, head) in LDS: 100 KB -> ONE workgroup per CU, so the staging latency of every workgroup is exposed and
+// 13 query tiles on 14 waves leave one SIMD with 4 tiles and three with 3 (measured 53 % of the MFMA issue time).  Here the
+// keys STREAM through LDS in blocks of 64 (4 key tiles, K + V = 32 KB), double-buffered: block b + 1 is on its way (LDS-DMA)
+// while block b is multiplied, one barrier per block, and at 64 KB two workgroups of 7 waves share a CU (26 query tiles
+// over the 4 SIMDs).  Each wave keeps Q, the running maximum, sum and O^T of its (up to two) query tiles in registers
+// across the blocks (online softmax: later blocks rescale by exp(m_old - m_new)); operand layouts, swizzles and MFMA
+// order are those of attn_f32_mfma_kernel.
+// ABL (tools/attn_lab_f32.hip only): 1 = no exponentials, 2 = V operand not read from LDS, 3 = K operand not read from
+// LDS, 4 = no staging, 5 = no P.V products, 6 = no S products.  (Per-wave s_setprio to break the phase lock of the
+// waves of a SIMD: measured +1 %, not kept.)
+template <int NW, int ABL = 0>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4)))  // <= 128 VGPRs: two workgroups per CU
+attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads) {
+  constexpr int BT = 4, BK = BT * 16;          // key tiles / keys per block
+  constexpr int OFF_V = BK * 256, VPIECE = 1024 + 64, BUF = OFF_V + (BK / 4) * VPIECE;
+  constexpr int NPIECE = (2 * BK / 4 + NW - 1) / NW;   // 1 KiB pieces (4 rows of K or V) per wave and block
+  constexpr int QPW = 2;                        // query tiles per wave (13 tiles on 7 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int D = heads * 64;
+  const long ld = 3L * D;
+  const float* base = qkv + (long)seq * S * ld + h * 64;
+  const int r = lane & 15, g = lane >> 4;
+  const int nqt = (S + 15) >> 4;
+  const int nblk = (S + BK - 1) / BK;
+
+  // K: 1 KiB pieces of 4 keys, chunk c of key k stored at chunk c ^ (k & 15) (b128 fragment reads of 16 keys x one chunk
+  // are conflict-free).  V: pieces of 4 keys at a stride of 1024 + 64 bytes, rows unpermuted: the four lane groups of a
+  // P.V operand read (keys 4 g + e: row e of four consecutive pieces) land in four different quarter-banks, and the whole
+  // address is one lane-dependent base plus compile-time offsets.
+  auto stage = [&](int blk) {  // keys [blk * BK, blk * BK + BK): lane l of a 4-row piece -> row l >> 4, chunk l & 15
+    const int prow = lane >> 4, pch = lane & 15;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int p = wave + j * NW;          // pieces 0..15: K, 16..31: V
+      if (p < 2 * BK / 4) {
+        const int isv = p >= BK / 4, piece = p - (isv ? BK / 4 : 0);
+        const int row = piece * 4 + prow;
+        const int srow = min(blk * BK + row, S - 1);  // padded keys read a valid row; they are masked
+        const float* src = base + (isv ? 2 * D : D) + (long)srow * ld + ((isv ? pch : pch ^ (row & 15)) << 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (blk & 1) * BUF + (isv ? OFF_V + piece * VPIECE : piece * 1024)),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  if (ABL != 4) stage(0);
+
+  // lane-dependent parts of the LDS addresses: K fragment (S^T A-operand) row r, chunk (4 c + g) ^ r;
+  // V element (P.V A-operand) key 4 g + e of the tile, float 16 n + r: piece g of the tile, row e
+  int koff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) koff[c] = r * 256 + (((4 * c + g) ^ r) << 4);
+  const int voff = OFF_V + g * VPIECE + r * 4;
+
+  f32x4 o[QPW][4], qf[QPW][4];
+  float mrun[QPW], lrun[QPW];
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    mrun[qi] = kNegInf;
+    lrun[qi] = 0.f;
+    const float* qrow = base + (long)min((wave + qi * NW) * 16 + r, S - 1) * ld + 4 * g;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[qi][c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c) * 0.125f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[qi][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int blk = 0; blk < nblk; ++blk) {
+    if (ABL != 4) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of block blk (issued a whole block ago)
+      __syncthreads();  // block blk is complete, and nobody reads the other buffer any more
+      if (blk + 1 < nblk) stage(blk + 1);
+    }
+    const char* kv = smem + (blk & 1) * BUF;
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+      const int qt = wave + qi * NW;
+      if (qt < nqt) {
+        f32x4 sT[BT];
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          if (blk * BK + t * 16 < S) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 kf = ABL == 3 ? qf[qi][(c + t) & 3] : *reinterpret_cast<const f32x4*>(kv + t * 4096 + koff[c]);
+              if (ABL == 6) { acc += kf * qf[qi][c]; continue; }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[qi][c][e], acc, 0, 0, 0);
+            }
+          }
+          sT[t] = acc;
+        }
+        float mx = mrun[qi];
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+          if (blk * BK + t * 16 + 16 > S) {  // wave-uniform: only the tile that straddles S (and the ones past it) mask
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (blk * BK + t * 16 + 4 * g + e >= S) sT[t][e] = kNegInf;
+          }
+          mx = fmaxf(fmaxf(mx, fmaxf(sT[t][0], sT[t][1])), fmaxf(sT[t][2], sT[t][3]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // finite from the first block on (key 0 is never masked)
+        const float alpha = exp_neg_f32(mrun[qi] - mx);  // exp(-inf) = 0 on the first block
+        mrun[qi] = mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = ABL == 1 ? sT[t][e] - mx : exp_neg_f32(sT[t][e] - mx);
+            sT[t][e] = p;
+            sum += p;
+          }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        lrun[qi] = lrun[qi] * alpha + sum;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[qi][n] *= alpha;
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+          if (blk * BK + t * 16 >= S) continue;  // every P of the tile is zero
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              const float vf = ABL == 2 ? qf[qi][n][e] : *reinterpret_cast<const float*>(kv + voff + t * 4 * VPIECE + e * 256 + n * 64);
+              if (ABL == 5) { o[qi][n][e] += vf * sT[t][e]; continue; }
+              o[qi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sT[t][e], o[qi][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    const int query = (wave + qi * NW) * 16 + r;
+    if (query < S) {
+      const float inv = 1.f / lrun[qi];
+      float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[qi][n] * inv;
+    }
+  }
+}
+
 // f32 parity kernel: thread per query (256 queries per workgroup), K/V rows broadcast from LDS in chunks of `kc` keys
 // (any sequence length; one chunk up to 256 keys), online softmax in key order.
 template <bool CAUSAL>
@@ -771,6 +926,14 @@ int launch_f32_mfma(const void* qkv, void* out, int n_seq, int S, int heads, hip
   return FC_OK;
 }
 
+int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
+  constexpr int NW = 7, lds = 2 * (64 * 256 + 16 * (1024 + 64));  // two 33 KiB buffers (64 keys of K and V): two workgroups per CU
+  hipLaunchKernelGGL((attn_f32_blocks_kernel<NW>), dim3(n_seq * heads), dim3(NW * 64), lds, st, (const float*)qkv,
+                     (float*)out, S, heads);
+  FC_CHECK_LAUNCH("attention(f32 blocks)");
+  return FC_OK;
+}
+
 template <int NKT>
 int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
   constexpr int NK = NKT * 16;
@@ -810,9 +973,12 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
     if (S <= 96)
       return causal ? launch_f32_mfma<6, 6, true>(qkv, out, n_seq, S, heads, stream)
                     : launch_f32_mfma<6, 6, false>(qkv, out, n_seq, S, heads, stream);
-    if (S <= 224)
+    if (S <= 224) {
+      static const bool one_block = getenv("FITCLIP_ATTN_F32_ONE_BLOCK") != nullptr;  // A/B switch: first generation
+      if (!causal && !one_block) return launch_f32_blocks(qkv, out, n_seq, S, heads, stream);
       return causal ? launch_f32_mfma<14, 14, true>(qkv, out, n_seq, S, heads, stream)
                     : launch_f32_mfma<14, 14, false>(qkv, out, n_seq, S, heads, stream);
+    }
     return causal ? launch_f32_mfma<18, 8, true>(qkv, out, n_seq, S, heads, stream)
                   : launch_f32_mfma<18, 8, false>(qkv, out, n_seq, S, heads, stream);
   }
