@@ -649,6 +649,28 @@ __global__ void __launch_bounds__(NW * 64) attn_f32_mfma_kernel(const float* __r
 // ABL (tools/attn_lab_f32.hip only): 1 = no exponentials, 2 = V operand not read from LDS, 3 = K operand not read from
 // LDS, 4 = no staging, 5 = no P.V products, 6 = no S products.  (Per-wave s_setprio to break the phase lock of the
 // waves of a SIMD: measured +1 %, not kept.)
+// exp(x) for FINITE x <= 0 (no masked keys in the tile): exp_neg_f32 (common.h) without its clamp and select
+__device__ __forceinline__ float exp_neg_finite_f32(float x) {
+  constexpr float kHi = 1.4426950216293335f, kLo = 1.925963033500011e-08f;
+  const float t = x * kHi;
+  const float r = __builtin_fmaf(x, kLo, __builtin_fmaf(x, kHi, -t));
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.6931471805599453f, e);
+}
+// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} on v_permlane32_swap / v_permlane16_swap (no LDS round trip)
+__device__ __forceinline__ float max_over_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_over_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int NW, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4)))  // <= 128 VGPRs: two workgroups per CU
 attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads) {
@@ -717,6 +739,8 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
       if (blk + 1 < nblk) stage(blk + 1);
     }
     const char* kv = smem + (blk & 1) * BUF;
+    const char* kfrag[4] = {kv + koff[0], kv + koff[1], kv + koff[2], kv + koff[3]};  // one add per block, not per read
+    const char* vfrag = kv + voff;
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
       const int qt = wave + qi * NW;
@@ -728,7 +752,7 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
           if (blk * BK + t * 16 < S) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const f32x4 kf = ABL == 3 ? qf[qi][(c + t) & 3] : *reinterpret_cast<const f32x4*>(kv + t * 4096 + koff[c]);
+              const f32x4 kf = ABL == 3 ? qf[qi][(c + t) & 3] : *reinterpret_cast<const f32x4*>(kfrag[c] + t * 4096);
               if (ABL == 6) { acc += kf * qf[qi][c]; continue; }
 #pragma unroll
               for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[qi][c][e], acc, 0, 0, 0);
@@ -746,23 +770,22 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
           }
           mx = fmaxf(fmaxf(mx, fmaxf(sT[t][0], sT[t][1])), fmaxf(sT[t][2], sT[t][3]));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // finite from the first block on (key 0 is never masked)
+        mx = max_over_lane_groups(mx);            // finite from the first block on (key 0 is never masked)
         const float alpha = exp_neg_f32(mrun[qi] - mx);  // exp(-inf) = 0 on the first block
         mrun[qi] = mx;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < BT; ++t) {
+          if (blk * BK + t * 16 + 16 > S) {       // tiles with masked keys: the guarded exponential (exp(-inf) = 0)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float p = ABL == 1 ? sT[t][e] - mx : exp_neg_f32(sT[t][e] - mx);
-            sT[t][e] = p;
-            sum += p;
+            for (int e = 0; e < 4; ++e) sT[t][e] = ABL == 1 ? sT[t][e] - mx : exp_neg_f32(sT[t][e] - mx);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sT[t][e] = ABL == 1 ? sT[t][e] - mx : exp_neg_finite_f32(sT[t][e] - mx);
           }
+          sum += (sT[t][0] + sT[t][1]) + (sT[t][2] + sT[t][3]);
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        lrun[qi] = lrun[qi] * alpha + sum;
+        lrun[qi] = lrun[qi] * alpha + sum;        // per lane group; the four groups are added at the end
 #pragma unroll
         for (int n = 0; n < 4; ++n) o[qi][n] *= alpha;
 #pragma unroll
@@ -772,7 +795,7 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
           for (int e = 0; e < 4; ++e) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-              const float vf = ABL == 2 ? qf[qi][n][e] : *reinterpret_cast<const float*>(kv + voff + t * 4 * VPIECE + e * 256 + n * 64);
+              const float vf = ABL == 2 ? qf[qi][n][e] : *reinterpret_cast<const float*>(vfrag + t * 4 * VPIECE + e * 256 + n * 64);
               if (ABL == 5) { o[qi][n][e] += vf * sT[t][e]; continue; }
               o[qi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sT[t][e], o[qi][n], 0, 0, 0);
             }
@@ -784,8 +807,8 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
     const int query = (wave + qi * NW) * 16 + r;
+    const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
     if (query < S) {
-      const float inv = 1.f / lrun[qi];
       float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
 #pragma unroll
       for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[qi][n] * inv;

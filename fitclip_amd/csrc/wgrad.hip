@@ -21,7 +21,10 @@ namespace fc {
 
 namespace {
 
-constexpr int TN_BK = 16;  // m-rows per LDS stage
+#ifndef FITCLIP_TN_BK
+#define FITCLIP_TN_BK 16
+#endif
+constexpr int TN_BK = FITCLIP_TN_BK;  // m-rows per LDS stage
 
 struct TnArgs {
   const float* A;
