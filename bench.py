@@ -228,7 +228,7 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if D.collectives_active():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -248,7 +248,7 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
     fence()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
                            device=device if backend == "nccl" else "cpu")
-    if world > 1:
+    if D.collectives_active():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
     timed_records = enc.model.profile_records()
@@ -361,7 +361,10 @@ def main() -> None:
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # FITCLIP_FORCE_COLLECTIVES=1 under a one-rank torch.distributed.run: the single-GPU rehearsal of the RCCL path
+    # (process group, broadcast, all-gathers, barrier and all-reduce all go through the library)
+    grouped = world > 1 or (os.environ.get("FITCLIP_FORCE_COLLECTIVES") == "1" and "WORLD_SIZE" in os.environ)
+    if grouped:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -381,7 +384,7 @@ def main() -> None:
     if not args.no_plant:
         # one model for all ranks: rank 0 plants on its own clips, everybody receives the three tensors
         planted = plant_retrieval_weights(sd, video, ids, dims, device, block=args.cpu_sample_clips) if rank == 0 else None
-        if world > 1:
+        if grouped:
             for k in PLANTED:
                 t = torch.from_numpy(planted[k]).to(device) if rank == 0 else torch.empty(sd[k].shape, device=device)
                 if args.backend == "gloo":
@@ -406,7 +409,8 @@ def main() -> None:
                    "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate" if args.precision == "fp32"
                                  else "bf16 MFMA operands, fp32 accumulate / residual / LayerNorm / softmax statistics",
                    "prune_last_block": bool(args.prune_last_block),
-                   "sharding": f"clips over {world} rank(s), one RCCL all-gather of embeddings"},
+                   "sharding": f"clips over {world} rank(s), one RCCL all-gather of embeddings",
+                   "collectives": f"{args.backend} process group, {world} rank(s)" if grouped else "none (single process)"},
         "roofline": head["roofline"], "roofline_all_gemms": head["roofline_all_gemms"],
         "roofline_whole_path": head["roofline_whole_path"], "roofline_vit_forward": head["roofline_vit_forward"],
         "time_split": head["time_split"],
@@ -482,7 +486,7 @@ def main() -> None:
                 "ranks_identical": bool(torch.equal(r16.long(), ref_ranks.long()))}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -26,6 +26,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything init
 from pathlib import Path
 from typing import Any, Dict, Mapping
 
+import numpy as np
 import torch
 import yaml
 
@@ -40,6 +41,7 @@ DEFAULTS: Dict[str, Any] = {
     # command=train (config/teacher_student_trainer.yaml + config/data/mixed_batch_*.yaml): per-rank batch composition
     "steps": 10, "n_labeled": 8, "n_unlabeled": 8, "lr": 3e-6, "fit_temperature": False, "output_path": "predictions.pt",
     "repeat_batch": False,  # train: every step sees the first batch again (overfitting smoke test)
+    "labeled_clips": 32, "unlabeled_clips": 256,  # train: sizes of the two synthetic sources the mixed batches draw from
 }
 
 
@@ -125,7 +127,8 @@ def train(cfg: Mapping[str, Any]) -> Dict[str, Any]:
     """`command=train` with `encoder=teacher_student_*`: the distillation loop of the reference
     (config/teacher_student_trainer.yaml -> TeacherStudentLightningModule; optimiser torch.optim.AdamW lr 3e-6,
     config/trainer.yaml:21-23; temperatures init 0.015, fit_temperature false, :17-20) over synthetic mixed batches
-    (`n_labeled` + `n_unlabeled` clips per rank and step, as config/data/mixed_batch_*.yaml composes them)."""
+    (`n_labeled` + `n_unlabeled` clips per rank and step out of `labeled_clips` / `unlabeled_clips`, composed as
+    config/data/mixed_batch_*.yaml does: fitclip_amd/mixed_batch.py)."""
     from .training import TeacherStudentTrainer
     rank, world = D.world()
     device = _device(cfg)
@@ -139,12 +142,30 @@ def train(cfg: Mapping[str, Any]) -> Dict[str, Any]:
                                    fit_temperature=bool(cfg["fit_temperature"]))
     dims = student.model.dims
     per = cfg["n_labeled"] + cfg["n_unlabeled"]
-    names = ["labeled"] * cfg["n_labeled"] + ["unlabeled"] * cfg["n_unlabeled"]
-    losses = []
+    # batches of a fixed composition drawn round-robin from the two sources, the small one cycling, and dealt to the
+    # ranks batch by batch (MixedBatchDataModule.train_dataloader, data_module_group.py:124-166); clip ids are the
+    # indices into the concatenated sources
+    from torch.utils.data import RandomSampler
+    from .mixed_batch import MixedBatchSampler
+    sizes = {"labeled": max(cfg["labeled_clips"], cfg["n_labeled"]), "unlabeled": max(cfg["unlabeled_clips"], cfg["n_unlabeled"])}
+    sequence = {k: n for k, n in (("labeled", cfg["n_labeled"]), ("unlabeled", cfg["n_unlabeled"])) if n > 0}
+    generator = torch.Generator().manual_seed(cfg["seed"])  # the same shuffles on every rank
+    sampler = MixedBatchSampler({k: RandomSampler(range(sizes[k]), generator=generator) for k in sequence}, sequence,
+                                rank=rank, world=world)
+    epoch = iter(sampler)
+    losses, first = [], None
     for step in range(cfg["steps"]):
-        first = ((0 if cfg["repeat_batch"] else step) * world + rank) * per
-        video = torch.from_numpy(synth.make_video(per, cfg["num_frames"], dims, cfg["seed"], first)).to(device)
-        ids = torch.from_numpy(synth.make_text(per, dims, cfg["seed"], first)).to(device)
+        if first is None or not cfg["repeat_batch"]:
+            try:
+                clip_ids, names = next(epoch)
+            except StopIteration:  # next epoch: the sub-samplers reshuffle
+                epoch = iter(sampler)
+                clip_ids, names = next(epoch)
+            first = first or (clip_ids, names)
+        if cfg["repeat_batch"]:
+            clip_ids, names = first
+        video = torch.from_numpy(np.concatenate([synth.make_video(1, cfg["num_frames"], dims, cfg["seed"], i) for i in clip_ids])).to(device)
+        ids = torch.from_numpy(np.concatenate([synth.make_text(1, dims, cfg["seed"], i) for i in clip_ids])).to(device)
         losses.append(module.fit_step({"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
                                        "text_teacher": {"input_ids": ids}, "dataset": names}))
     return {"steps": cfg["steps"], "clips_per_step": per * world, "loss/train": losses,

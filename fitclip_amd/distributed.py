@@ -10,6 +10,7 @@ padding / duplication of its DDP sampler (the shards here are exact).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Sequence, Tuple
 
 import numpy as np
@@ -21,6 +22,15 @@ def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def collectives_active() -> bool:
+    """True when the exchange steps have to run: more than one rank - or a ONE-rank process group under
+    FITCLIP_FORCE_COLLECTIVES=1, the single-GPU rehearsal of the RCCL path (every collective then goes through the
+    library with the production tensors, shapes and streams, although there is nobody to exchange with)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("FITCLIP_FORCE_COLLECTIVES") == "1"
 
 
 def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -38,7 +48,7 @@ def all_gather_rows(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
     """Concatenation over ranks of `local` ([counts[rank], ...]), in rank order - the flattened
     `[world, B, ...] -> [world * B, ...]` view of the reference wrapper (tensor_utils.py:58-60), for ragged shards."""
     rank, world_size = world()
-    if world_size == 1:
+    if not collectives_active():
         return local
     assert local.shape[0] == counts[rank], (local.shape, counts, rank)
     biggest = max(counts)
@@ -63,8 +73,7 @@ def all_gather_many(tensors: Sequence[torch.Tensor], counts: Sequence[int]) -> L
     """`all_gather_rows` of several [n_local, d_i] tensors in ONE collective (they are packed side by side into one
     [n_local, sum d_i] buffer): the (student video, student text, teacher video, teacher text) tuple the reference's
     wrapper walks tensor by tensor (tensor_utils.py:48-66, teacher_student.py:143)."""
-    rank, world_size = world()
-    if world_size == 1:
+    if not collectives_active():
         return list(tensors)
     widths = [t.shape[1] for t in tensors]
     gathered = all_gather_rows(torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1), counts)
@@ -74,8 +83,7 @@ def all_gather_many(tensors: Sequence[torch.Tensor], counts: Sequence[int]) -> L
 def all_reduce_sum_(t: torch.Tensor, async_op: bool = False):
     """In-place sum over the ranks (gradient exchange of the training step: RCCL all-reduce of a slice of the flat
     gradient buffer).  Returns the work handle when `async_op` (None if there is nothing to wait for)."""
-    rank, world_size = world()
-    if world_size == 1 or t.numel() == 0:
+    if not collectives_active() or t.numel() == 0:
         return None
     if t.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal of the multi-rank path: stage through the host
         host = t.cpu()

@@ -87,7 +87,7 @@ class TextVideoRetrievalModule(VideoTextModule):
                                       lambda s, off: ops.ranks(s, off))
         num = torch.tensor([sum(l * b for l, b in self._losses), float(sum(b for _, b in self._losses))],
                            dtype=torch.float64, device=encoded_videos.device)
-        if world_size > 1:
+        if D.collectives_active():
             torch.distributed.all_reduce(num)
         metrics["loss/val"] = float(num[0] / num[1])
         self._outputs, self._losses = [], []
@@ -110,7 +110,7 @@ class TeacherStudentModule(VideoTextModule):
     def dataset_step_end(self, output: Tuple[TYPE_OUTPUT, TYPE_OUTPUT], labeled: bool) -> torch.Tensor:
         (video, text), (teacher_video, teacher_text) = output
         rank, world_size = D.world()
-        if world_size > 1:
+        if D.collectives_active():
             counts = [len(video)] * world_size  # training batches are equal-sized per rank (DDP)
             video, text, teacher_video, teacher_text = D.all_gather_many(
                 (video, text, teacher_video, teacher_text), counts)  # one collective for the four embeddings

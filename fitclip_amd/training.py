@@ -160,9 +160,8 @@ class StudentTrainer:
                                                        arena.data_ptr(), arena.numel(), scratch.data_ptr(),
                                                        scratch.numel(), int(acc or i > 0), stream),
                            "fc_encode_text_backward")
-            world = D.world()[1]
             lo, hi = self.visual_span
-            if reduce_across_ranks and world > 1:
+            if reduce_across_ranks and D.collectives_active():
                 handles += [D.all_reduce_sum_(self.grads[:lo], async_op=True),
                             D.all_reduce_sum_(self.grads[hi:], async_op=True)]
             for i, (s, n, arena) in enumerate(st["v"]):
@@ -170,7 +169,7 @@ class StudentTrainer:
                 _lib.check(lib.fc_encode_image_backward(rt.handle, dzv[s:].data_ptr(), n, arena.data_ptr(),
                                                         arena.numel(), scratch.data_ptr(), scratch.numel(),
                                                         int(acc or i > 0), stream), "fc_encode_image_backward")
-            if reduce_across_ranks and world > 1:
+            if reduce_across_ranks and D.collectives_active():
                 handles.append(D.all_reduce_sum_(self.grads[lo:hi], async_op=True))
                 for h in handles:
                     if h is not None:

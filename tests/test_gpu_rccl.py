@@ -1,0 +1,53 @@
+"""The exchange steps of the path on the RCCL library itself.  A one-GPU box cannot hold two RCCL ranks (the library
+refuses two ranks on one device), so this is the part of SURVEY 8(a10)/(e) that CAN run here: a one-rank "nccl" process
+group with FITCLIP_FORCE_COLLECTIVES=1, through which evaluate, the training step and `bench.py` issue every collective
+of the multi-GPU path on device tensors.  The multi-rank semantics (shard order, ragged shards, gradient sums) are
+covered by the gloo tests (tests/test_distributed_cpu.py, test_gpu_training.py::test_two_rank_*)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _launch(script_args, extra_env=None, timeout=900):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "FITCLIP_FORCE_COLLECTIVES": "1", **(extra_env or {})})
+    # fresh children: the rank process is started by torch.distributed.run before anything in it has touched the GPU
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), *script_args], capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=str(ROOT))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    return json.loads([line for line in run.stdout.splitlines() if line.startswith("{")][-1])
+
+
+def test_every_collective_of_the_path_runs_on_rccl():
+    out = _launch([str(ROOT / "tests" / "workers" / "rccl_one_rank.py")])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    for key in ("gather_f32", "gather_i32", "gather_many", "all_reduce_async", "broadcast_barrier"):
+        assert out[key] is True, key
+    assert out["evaluate"]["equal"], out["evaluate"]
+    # the step is deterministic up to the atomics-ordered token-embedding gradient: where that noise decides the sign of
+    # an AdamW update two runs differ by up to 2 lr (lr = 1e-3 in the worker), with or without collectives
+    a, b = out["train"]["losses_rccl"], out["train"]["losses_plain"]
+    assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-5 * abs(b[1]), out["train"]
+    assert out["train"]["max_param_delta"] <= 2.5e-3
+
+
+def test_bench_runs_its_rccl_path_on_one_rank():
+    """`bench.py` under a one-rank torch.distributed.run with forced collectives: process group on the device,
+    broadcast of the planted tensors, all-gathers inside the timed steps, barrier + MAX all-reduce around them."""
+    out = _launch([str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--clips", "16", "--frames", "2",
+                   "--no-cpu-baseline", "--no-bf16-mode"])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["collectives"].startswith("nccl process group"), out["config"]
+    assert 0.0 <= out["retrieval"]["r1"] <= 1.0 and out["retrieval"]["n"] == 16

@@ -128,7 +128,7 @@ def test_rectangular_kd_loss_and_backward(rows, cols):
     ref = O.teacher_student_nce_loss(x, y)
     ref.backward()
     sd, td = s.to(DEV), t.to(DEV)
-    assert abs(float(ops.teacher_student_nce_loss(sd, td)) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert abs(float(ops.teacher_student_nce_loss(sd, td)) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
     lib = _lib.load()
     ds, ws = torch.empty_like(sd), torch.empty(3 * (rows + cols), device=DEV)
     _lib.check(lib.fc_kd_loss_backward(sd.data_ptr(), td.data_ptr(), rows, cols, 2.0, ds.data_ptr(), ws.data_ptr(), _stream()))
