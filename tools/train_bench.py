@@ -1,11 +1,12 @@
 #!/usr/bin/env python
 """Times the KD training step (student fp32 forward with kept activations + frozen teacher forward + loss + backward +
 AdamW) at one rank's share of BASELINE configs[4] (64 clips x 8 frames + 64 texts per GPU, ViT-B/16) and prints one JSON
-line: ms per step, clip-pairs/s, and the achieved TFLOP/s against the fp32-input MFMA peak (FLOPs counted as 3x the
-student's forward GEMM/attention FLOPs + 1x the teacher's).  `--profile` wraps nothing: run it under rocprofv3 with
-the program directly after `--`.
+line: ms per step, clip-pairs/s, and the achieved TFLOP/s against the fp32-input MFMA peak.  FLOPs: 3x the student's
+forward GEMM/attention FLOPs (forward + dgrad + wgrad) + 1x the frozen teacher's forward when it runs in fp32 (the
+reference's precision, the default); `--teacher-precision bf16` is the labelled faster variant, its teacher FLOPs are
+not counted.  Run it under rocprofv3 with the program directly after `--`.
 
-    python tools/train_bench.py [--clips 64] [--frames 8] [--steps 3] [--teacher-precision bf16]
+    python tools/train_bench.py [--clips 64] [--frames 8] [--steps 3] [--teacher-precision fp32|bf16]
 """
 import argparse
 import json
@@ -31,7 +32,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--teacher-precision", default="bf16")
+    ap.add_argument("--teacher-precision", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     d = synth.VIT_B_16
@@ -62,12 +63,14 @@ def main():
         torch.cuda.synchronize(); phases["optimizer"] += time.perf_counter() - t
     el = time.perf_counter() - t0
     fwd = a.clips * (a.frames * GF_PER_FRAME + GF_PER_TEXT)
-    student_flops = 3 * fwd
+    flops = (4 if a.teacher_precision == "fp32" else 3) * fwd
     res = {"metric": "KD training step, one rank's share of BASELINE configs[4]", "clips": a.clips, "frames": a.frames,
+           "teacher_precision": a.teacher_precision,
            "ms_per_step": round(el / a.steps * 1e3, 2), "pairs_per_s": round(a.clips * a.steps / el, 2),
-           "student_tflops_fp32_mfma": round(student_flops * a.steps / el / 1e12, 2),
-           "frac_of_157.3": round(student_flops * a.steps / el / 1e12 / 157.3, 4),
-           "note": "student FLOPs = 3 x forward (dgrad + wgrad); the teacher forward (%s) is inside the step time but not in the FLOP count" % a.teacher_precision,
+           "tflops_fp32_mfma": round(flops * a.steps / el / 1e12, 2),
+           "frac_of_157.3": round(flops * a.steps / el / 1e12 / 157.3, 4),
+           "note": ("FLOPs = 3 x student forward (forward + dgrad + wgrad) + 1 x fp32 teacher forward" if a.teacher_precision == "fp32" else
+                    "FLOPs = 3 x student forward; the bf16 teacher forward is inside the step time but not in the FLOP count"),
            "phases_ms": {k: round(v / a.steps * 1e3, 2) for k, v in phases.items()}, "loss": loss,
            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     print(json.dumps(res))
