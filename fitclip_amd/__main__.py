@@ -42,6 +42,7 @@ DEFAULTS: Dict[str, Any] = {
     "steps": 10, "n_labeled": 8, "n_unlabeled": 8, "lr": 3e-6, "fit_temperature": False, "output_path": "predictions.pt",
     "repeat_batch": False,  # train: every step sees the first batch again (overfitting smoke test)
     "labeled_clips": 32, "unlabeled_clips": 256,  # train: sizes of the two synthetic sources the mixed batches draw from
+    "teacher_on_labeled": False,  # train: also run the teacher on the labeled rows (its output there is never read)
 }
 
 
@@ -139,7 +140,8 @@ def train(cfg: Mapping[str, Any]) -> Dict[str, Any]:
         raise SystemExit("command=train needs an encoder config with `teacher` and `student` (e.g. teacher_student_vit_b_16)")
     teacher, student = instantiate(node["teacher"]).to(device), instantiate(node["student"]).to(device)
     module = TeacherStudentTrainer(student, teacher, init_temperature=cfg["init_temperature"], lr=cfg["lr"],
-                                   fit_temperature=bool(cfg["fit_temperature"]))
+                                   fit_temperature=bool(cfg["fit_temperature"]),
+                                   teacher_on_labeled=bool(cfg["teacher_on_labeled"]))
     dims = student.model.dims
     per = cfg["n_labeled"] + cfg["n_unlabeled"]
     # batches of a fixed composition drawn round-robin from the two sources, the small one cycling, and dealt to the

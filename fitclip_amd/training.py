@@ -210,8 +210,15 @@ class TeacherStudentTrainer(TeacherStudentModule):
                  dataset_names: Iterable[str] = ("labeled", "unlabeled"), init_temperature: float = 0.05,
                  min_temperature: float = 0.001, fit_temperature: bool = True, lr: float = 3e-6,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 prompts: Optional[Iterable[str]] = None, **trainer_kwargs: Any) -> None:
+                 prompts: Optional[Iterable[str]] = None, teacher_on_labeled: bool = False,
+                 **trainer_kwargs: Any) -> None:
         super().__init__(encoder, teacher, init_temperature, min_temperature)
+        # The reference runs the teacher over the whole batch (teacher_student.py:94-96) but only ever reads its
+        # embeddings of the UNLABELED part (`_dataset_step_end`, :150-160: the labeled part's loss is `self.loss(scores)`
+        # of the student alone).  By default the teacher therefore skips the labeled rows (same loss, same gradients,
+        # half the teacher forward at the usual 1:1 composition); their teacher entries in `training_step`'s output
+        # are zeros.  `teacher_on_labeled=True` restores the reference's literal schedule.
+        self.teacher_on_labeled = bool(teacher_on_labeled)
         self.dataset_names = list(dataset_names)
         assert len(self.dataset_names) == 2, "The current implementation needs exactly 2 datasets."  # :57
         if labeled_dataset_loss_share is None:                                                       # :61-67
@@ -265,7 +272,29 @@ class TeacherStudentTrainer(TeacherStudentModule):
             text_lengths[idx] = self.tokenized_prompts.shape[0]
         sv, st = self.student.forward(batch["video_student"], {"input_ids": text_student})
         with torch.no_grad():
-            tv, tt = self.teacher(video=batch["video_teacher"], text={"input_ids": text_teacher})
+            if self.teacher_on_labeled:
+                tv, tt = self.teacher(video=batch["video_teacher"], text={"input_ids": text_teacher})
+            else:
+                # rows of the datasets whose loss reads the teacher; each dataset is one contiguous run of the batch
+                vr, tr, v0, t0 = [], [], 0, 0
+                for key, nv, nt in zip(keys, lengths, text_lengths):
+                    if key != self.labeled_dataset_name:
+                        vr.append((v0, v0 + nv))
+                        tr.append((t0, t0 + nt))
+                    v0, t0 = v0 + nv, t0 + nt
+                pick = lambda x, runs: x[runs[0][0]:runs[0][1]] if len(runs) == 1 else torch.cat([x[a:b] for a, b in runs])  # noqa: E731
+                pv, pt = self.teacher(video=pick(batch["video_teacher"], vr), text={"input_ids": pick(text_teacher, tr)})
+                tv = pv.new_zeros((sv.shape[0], pv.shape[1]))
+                tt = pt.new_zeros((st.shape[0], pt.shape[1]))
+                if vr:
+                    o = 0
+                    for a, b in vr:
+                        tv[a:b] = pv[o:o + b - a]
+                        o += b - a
+                    o = 0
+                    for a, b in tr:
+                        tt[a:b] = pt[o:o + b - a]
+                        o += b - a
         out, v0, t0 = {}, 0, 0
         self._layout = []
         for key, nv, nt in zip(keys, lengths, text_lengths):
@@ -294,8 +323,15 @@ class TeacherStudentTrainer(TeacherStudentModule):
             stream = _lib.current_stream()
             for name, nv, nt in self._layout:
                 (v, t), (tv, tt) = output[name]
-                # one collective per distinct row count (one in all when videos and texts pair up)
-                if nv == nt:
+                # one collective per distinct row count (one in all when videos and texts pair up); the labeled part's
+                # teacher embeddings are never read, so they do not travel
+                if name == self.labeled_dataset_name and not self.teacher_on_labeled:
+                    if nv == nt:
+                        v_all, t_all = D.all_gather_many((v.contiguous(), t.contiguous()), [nv] * world)
+                    else:
+                        v_all, t_all = D.all_gather_rows(v.contiguous(), [nv] * world), D.all_gather_rows(t.contiguous(), [nt] * world)
+                    tv_all = tt_all = None
+                elif nv == nt:
                     v_all, t_all, tv_all, tt_all = D.all_gather_many((v.contiguous(), t.contiguous(), tv.contiguous(),
                                                                       tt.contiguous()), [nv] * world)
                 else:

@@ -526,3 +526,36 @@ def test_checkpoint_and_resume_continue_the_same_run(tmp_path, tiny_state_dict):
     want = ClipVideoTextEncoder(build_clip({k[len("encoder.model."):]: v.numpy() for k, v in ckpt["state_dict"].items()
                                             if k.startswith("encoder.model.")}, precision="fp32", device=DEV)).encode_video(video)
     assert torch.equal(plain.encoder.encode_video(video), want)
+
+
+@pytest.mark.parametrize("labeled_first", [True, False])
+def test_teacher_skips_the_labeled_rows_without_changing_the_step(tiny_state_dict, labeled_first):
+    """The labeled part's loss never reads the teacher (teacher_student.py:150-160), so by default the teacher only
+    encodes the unlabeled rows.  Loss, both per-dataset losses, every gradient and the temperature gradients must equal
+    the reference's literal schedule (`teacher_on_labeled=True`), whichever dataset comes first in the batch; the
+    unlabeled teacher embeddings are the same, the labeled ones are zeros."""
+    d = synth.TINY
+    student_np = synth.perturbed_state_dict(tiny_state_dict, d, seed=5, rel=0.3)
+    n, n_lab = 10, 4
+    video = torch.from_numpy(synth.make_video(n, 2, d, seed=21))
+    ids = torch.from_numpy(synth.make_text(n, d, seed=21))
+    batch = _batch(video, ids, n_lab)
+    if not labeled_first:
+        batch["dataset"] = ["unlabeled"] * (n - n_lab) + ["labeled"] * n_lab
+    steps = {}
+    for literal in (True, False):
+        module = _trainer(student_np, tiny_state_dict, 0.05, teacher_on_labeled=literal)
+        out = module.training_step(dict(batch))
+        loss = module.training_step_end(out)
+        module.backward()
+        steps[literal] = (loss, dict(module.last_losses), module.student.grads.clone(), module.scale_grads.clone(), out)
+    a, b = steps[True], steps[False]
+    assert a[0] == b[0] and a[1] == b[1]
+    tok, tok_n = module.student.offsets["token_embedding.weight"], d.vocab_size * d.transformer_width
+    mask = torch.ones_like(a[2], dtype=torch.bool)  # the token-embedding gradient is an atomics-ordered sum
+    mask[tok:tok + tok_n] = False
+    assert torch.equal(a[2][mask], b[2][mask])
+    assert float((a[2] - b[2]).abs().max()) <= 1e-6 * float(a[2].abs().max())
+    assert torch.equal(a[3], b[3])
+    assert torch.equal(a[4]["unlabeled"][1][0], b[4]["unlabeled"][1][0]) and torch.equal(a[4]["unlabeled"][1][1], b[4]["unlabeled"][1][1])
+    assert not b[4]["labeled"][1][0].any() and not b[4]["labeled"][1][1].any() and a[4]["labeled"][1][0].any()
