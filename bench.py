@@ -33,6 +33,8 @@ The same JSON line carries
     device path over the whole batch, and on the CPU sample the device path ("gpu"), the oracle ("ref") and "delta".
   * "cpu_baseline": the CPU oracle (oracle/clip_oracle.py, kind "port") timed on this host's cores over a bounded
     sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample.
+  * `kd_training_step` (N = 1 only, after the timed region): the distillation training step at one
+    rank's share of BASELINE configs[4]; never part of `value`.
 """
 from __future__ import annotations
 
@@ -205,6 +207,45 @@ def load_traffic(precision, shape, epilogue):
     return None, "no PMC pass committed for this precision"
 
 
+def training_leg(sd, video, ids, args, dims, device, clips=64, steps=2):
+    """Outside the timed region, N = 1 only: the KD training step (aligner/teacher_student.py:99-183) at
+    one rank's share of BASELINE configs[4] - 64 clips x 8 frames + 64 captions, half labeled; student fp32 forward with
+    kept activations, frozen fp32 teacher forward over the rows whose loss reads it, NCE + KD losses, backward of both
+    towers, AdamW.  FLOPs = 3 x the student's forward + the teacher's forward over its rows."""
+    from fitclip_amd import synth
+    from fitclip_amd.clip_model import build_clip
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+    from fitclip_amd.training import TeacherStudentTrainer
+    n = min(clips, video.shape[0]) // 2 * 2
+    frames = video.shape[1]
+    torch.cuda.empty_cache()
+    student = ClipVideoTextEncoder(build_clip(synth.perturbed_state_dict(sd, dims, seed=5, rel=0.05), precision="fp32",
+                                              device=device), num_frames=frames)
+    teacher = ClipVideoTextEncoder(build_clip(sd, precision="fp32", device=device), num_frames=frames)
+    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=3e-7)
+    batch = {"video_student": video[:n], "text_student": {"input_ids": ids[:n]}, "video_teacher": video[:n],
+             "text_teacher": {"input_ids": ids[:n]}, "dataset": ["labeled"] * (n // 2) + ["unlabeled"] * (n // 2)}
+    losses = [module.fit_step(batch)]  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(module.fit_step(batch))
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    fwd = n * (frames * 35.127e9 + 5.960e9)
+    flops = 3.5 * fwd
+    out = {"ms_per_step": round(el * 1e3, 2), "pairs_per_s": round(n / el, 2), "dtype": "fp32",
+           "tflops": round(flops / el / 1e12, 2), "frac_of_fp32_mfma_peak": round(flops / el / 1e12 / PEAK_TFLOPS["fp32"], 4),
+           "config": f"{n} clips x {frames} frames + {n} captions per GPU, half labeled (one rank's share of BASELINE configs[4])",
+           "flops": "3 x student forward (forward, dgrad, wgrad) + fp32 teacher forward over the unlabeled half",
+           "weights": "random init (seed 42) teacher, student = teacher perturbed by 5 %; AdamW lr 3e-7 (the reference's "
+                      "3e-6 is tuned for pretrained towers and overshoots on random ones), the same batch every step",
+           "losses": [round(x, 6) for x in losses], "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    del module, student, teacher
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_mode(precision, sd, video, text, args, world, rank, device, backend, full_detail):
     """Warm-up, the timed K steps, and (untimed) the instrumented step + visual-tower passes for one precision."""
     import torch.distributed as dist
@@ -328,6 +369,8 @@ def main() -> None:
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the (untimed, N = 1 only) KD training-step measurement reported under `kd_training_step`")
     ap.add_argument("--no-plant", action="store_true", help="keep the purely random towers (chance-level retrieval)")
     ap.add_argument("--prune-last-block", action="store_true",
                     help="opt-in: only the pooled rows go through the MLP of the last block (identical embeddings)")
@@ -381,6 +424,7 @@ def main() -> None:
     text = {"input_ids": ids}
 
     weights_note = "random init (seed 42)"
+    unplanted = {k: sd[k].copy() for k in PLANTED}  # the training leg uses the plain random towers
     if not args.no_plant:
         # one model for all ranks: rank 0 plants on its own clips, everybody receives the three tensors
         planted = plant_retrieval_weights(sd, video, ids, dims, device, block=args.cpu_sample_clips) if rank == 0 else None
@@ -429,6 +473,9 @@ def main() -> None:
         b16["note"] = ("secondary mode: bf16 MFMA operands (fp32 accumulate, fp32 residual stream / LayerNorm / softmax "
                        "statistics); narrower than the reference's fp32, so it is never `value`")
         result["bf16_mode"] = b16
+
+    if rank == 0 and world == 1 and not args.no_train_leg and n_local >= 4:
+        result["kd_training_step"] = training_leg({**sd, **unplanted}, video, ids, args, dims, device)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import clip_oracle as O

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lr", type=float, default=3e-6, help="AdamW learning rate (config/trainer.yaml:21-23)")
     ap.add_argument("--teacher-precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--teacher-on-labeled", action="store_true",
                     help="run the teacher over the labeled half as well (the reference's literal schedule; its output is never read)")
@@ -42,14 +43,15 @@ def main():
     student_sd = synth.perturbed_state_dict(teacher_sd, d, seed=5, rel=0.05)
     student = ClipVideoTextEncoder(build_clip(student_sd, precision="fp32", device=dev), num_frames=a.frames)
     teacher = ClipVideoTextEncoder(build_clip(teacher_sd, precision=a.teacher_precision, device=dev), num_frames=a.frames)
-    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=3e-6, teacher_on_labeled=a.teacher_on_labeled)
+    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=a.lr, teacher_on_labeled=a.teacher_on_labeled)
     g = torch.Generator(device=dev).manual_seed(0)
     video = torch.randn((a.clips, a.frames, 3, 224, 224), generator=g, device=dev).clamp_(-2.5, 2.5)
     ids = torch.from_numpy(synth.make_text(a.clips, d, seed=1)).to(dev)
     batch = {"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
              "text_teacher": {"input_ids": ids}, "dataset": ["labeled"] * (a.clips // 2) + ["unlabeled"] * (a.clips - a.clips // 2)}
+    losses = []
     for _ in range(a.warmup):
-        loss = module.fit_step(batch)
+        losses.append(module.fit_step(batch))
     torch.cuda.synchronize()
     phases = {"forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
     t0 = time.perf_counter()
@@ -58,6 +60,7 @@ def main():
         out = module.training_step(batch)
         torch.cuda.synchronize(); phases["forward"] += time.perf_counter() - t; t = time.perf_counter()
         loss = module.training_step_end(out)
+        losses.append(loss)
         torch.cuda.synchronize(); phases["loss"] += time.perf_counter() - t; t = time.perf_counter()
         module.backward()
         torch.cuda.synchronize(); phases["backward"] += time.perf_counter() - t; t = time.perf_counter()
@@ -74,7 +77,7 @@ def main():
            "frac_of_157.3": round(flops * a.steps / el / 1e12 / 157.3, 4),
            "note": ("FLOPs = 3 x student forward (forward + dgrad + wgrad) + the fp32 teacher forward over the rows it runs on" if a.teacher_precision == "fp32" else
                     "FLOPs = 3 x student forward; the bf16 teacher forward is inside the step time but not in the FLOP count"),
-           "phases_ms": {k: round(v / a.steps * 1e3, 2) for k, v in phases.items()}, "loss": loss,
+           "phases_ms": {k: round(v / a.steps * 1e3, 2) for k, v in phases.items()}, "lr": a.lr, "losses (the same batch every step)": [round(x, 6) for x in losses],
            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     print(json.dumps(res))
 
