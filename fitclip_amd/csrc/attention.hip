@@ -161,6 +161,20 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(const bf16* __restrict__
   }
 }
 
+// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} on v_permlane32_swap / v_permlane16_swap (no LDS round trip)
+__device__ __forceinline__ float max_over_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_over_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 kernel, second generation (what the first profile asked for: the v1 kernel above spent its time in exposed
 // staging latency, 2-byte output stores and an unbalanced 13-tiles-over-4-waves split, not in MFMAs):
@@ -282,8 +296,7 @@ __global__ void __launch_bounds__(NWAVES * 64) attn_bf16_v2_kernel(const bf16* _
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(sT[t][0]), "v"(sT[t][1]));
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(sT[t][2]), "v"(sT[t][3]));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_over_lane_groups(mx);
       // p = exp2(s * c - mx * c): one packed fma per two scores, bare v_exp_f32, packed running sum
       const f32x2 c2 = {kScale, kScale}, nm2 = {-mx * kScale, -mx * kScale};
       f32x2 sum2 = {0.f, 0.f};
@@ -298,10 +311,7 @@ __global__ void __launch_bounds__(NWAVES * 64) attn_bf16_v2_kernel(const bf16* _
         sum2 += b;
         sT[t] = f32x4{a[0], a[1], b[0], b[1]};
       }
-      float sum = sum2[0] + sum2[1];
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      inv = __builtin_amdgcn_rcpf(sum);
+      inv = __builtin_amdgcn_rcpf(sum_over_lane_groups(sum2[0] + sum2[1]));
     }
     if (i == 0) {  // V has landed (every wave passes here exactly once, active or not)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -642,8 +652,8 @@ __global__ void __launch_bounds__(NW * 64) attn_f32_mfma_kernel(const float* __r
 // whole (sequence, head) in LDS: 100 KB -> ONE workgroup per CU, so the staging latency of every workgroup is exposed and
 // 13 query tiles on 14 waves leave one SIMD with 4 tiles and three with 3 (measured 53 % of the MFMA issue time).  Here the
 // keys STREAM through LDS in blocks of 64 (4 key tiles, K + V = 32 KB), double-buffered: block b + 1 is on its way (LDS-DMA)
-// while block b is multiplied, one barrier per block, and at 64 KB two workgroups of 7 waves share a CU (26 query tiles
-// over the 4 SIMDs).  Each wave keeps Q, the running maximum, sum and O^T of its (up to two) query tiles in registers
+// while block b is multiplied, one barrier per block, and at 66 KB two workgroups of 8 waves share a CU (16 waves: four
+// per SIMD).  Each wave keeps Q, the running maximum, sum and O^T of its (up to two) query tiles in registers
 // across the blocks (online softmax: later blocks rescale by exp(m_old - m_new)); operand layouts, swizzles and MFMA
 // order are those of attn_f32_mfma_kernel.
 // ABL (tools/attn_lab_f32.hip only): 1 = no exponentials, 2 = V operand not read from LDS, 3 = K operand not read from
@@ -657,27 +667,13 @@ __device__ __forceinline__ float exp_neg_finite_f32(float x) {
   const float e = __builtin_amdgcn_exp2f(t);
   return __builtin_fmaf(e, r * 0.6931471805599453f, e);
 }
-// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} on v_permlane32_swap / v_permlane16_swap (no LDS round trip)
-__device__ __forceinline__ float max_over_lane_groups(float x) {
-  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-__device__ __forceinline__ float sum_over_lane_groups(float x) {
-  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 template <int NW, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4)))  // <= 128 VGPRs: two workgroups per CU
 attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads) {
   constexpr int BT = 4, BK = BT * 16;          // key tiles / keys per block
   constexpr int OFF_V = BK * 256, VPIECE = 1024 + 64, BUF = OFF_V + (BK / 4) * VPIECE;
   constexpr int NPIECE = (2 * BK / 4 + NW - 1) / NW;   // 1 KiB pieces (4 rows of K or V) per wave and block
-  constexpr int QPW = 2;                        // query tiles per wave (13 tiles on 7 waves)
+  constexpr int QPW = 2;                        // query tiles per wave (13 tiles on 8 waves)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -688,6 +684,10 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
   const int r = lane & 15, g = lane >> 4;
   const int nqt = (S + 15) >> 4;
   const int nblk = (S + BK - 1) / BK;
+  // query tiles of this wave: `wave` and `NW + wave` (13 tiles on 8 waves: waves 0..4 carry two).  Handing the second
+  // tiles to different waves in alternate workgroups, so that two workgroups on a CU load different SIMDs, measured
+  // nothing (tools/attn_lab_f32 history); what matters is 8 waves = two per SIMD from every workgroup (7 waves: +13 %).
+  const int qtile[2] = {wave, NW + wave};
 
   // K: 1 KiB pieces of 4 keys, chunk c of key k stored at chunk c ^ (k & 15) (b128 fragment reads of 16 keys x one chunk
   // are conflict-free).  V: pieces of 4 keys at a stride of 1024 + 64 bytes, rows unpermuted: the four lane groups of a
@@ -725,7 +725,7 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
   for (int qi = 0; qi < QPW; ++qi) {
     mrun[qi] = kNegInf;
     lrun[qi] = 0.f;
-    const float* qrow = base + (long)min((wave + qi * NW) * 16 + r, S - 1) * ld + 4 * g;
+    const float* qrow = base + (long)min(qtile[qi] * 16 + r, S - 1) * ld + 4 * g;
 #pragma unroll
     for (int c = 0; c < 4; ++c) qf[qi][c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c) * 0.125f;
 #pragma unroll
@@ -743,7 +743,7 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
     const char* vfrag = kv + voff;
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
-      const int qt = wave + qi * NW;
+      const int qt = qtile[qi];
       if (qt < nqt) {
         f32x4 sT[BT];
 #pragma unroll
@@ -806,7 +806,7 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
   }
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
-    const int query = (wave + qi * NW) * 16 + r;
+    const int query = qtile[qi] * 16 + r;
     const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
     if (query < S) {
       float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
@@ -950,7 +950,7 @@ int launch_f32_mfma(const void* qkv, void* out, int n_seq, int S, int heads, hip
 }
 
 int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
-  constexpr int NW = 7, lds = 2 * (64 * 256 + 16 * (1024 + 64));  // two 33 KiB buffers (64 keys of K and V): two workgroups per CU
+  constexpr int NW = 8, lds = 2 * (64 * 256 + 16 * (1024 + 64));  // two 33 KiB buffers (64 keys of K and V): two workgroups per CU
   hipLaunchKernelGGL((attn_f32_blocks_kernel<NW>), dim3(n_seq * heads), dim3(NW * 64), lds, st, (const float*)qkv,
                      (float*)out, S, heads);
   FC_CHECK_LAUNCH("attention(f32 blocks)");
@@ -982,7 +982,13 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
     if (!use_v1) {
       if (S <= 32) return launch_bf16_v2<2, 2>(qkv, out, n_seq, S, heads, causal, stream);
       if (S <= 96) return launch_bf16_v2<6, 5>(qkv, out, n_seq, S, heads, causal, stream);
-      if (S <= 224) return launch_bf16_v2<14, 7>(qkv, out, n_seq, S, heads, causal, stream);
+      if (S <= 224) {
+        // 8 waves: every workgroup puts two waves on each SIMD (7 waves for the 13 query tiles of the ViT left one SIMD
+        // with a single wave per workgroup); FITCLIP_ATTN_7WAVES=1 is the A/B switch
+        static const bool seven = getenv("FITCLIP_ATTN_7WAVES") != nullptr;
+        return seven ? launch_bf16_v2<14, 7>(qkv, out, n_seq, S, heads, causal, stream)
+                     : launch_bf16_v2<14, 8>(qkv, out, n_seq, S, heads, causal, stream);
+      }
       if (causal) return fail(FC_EINVAL, "attention(bf16): causal attention over %d > 224 tokens is not supported", S);
       return launch_bf16_flash(qkv, out, n_seq, S, heads, stream);
     }

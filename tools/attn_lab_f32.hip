@@ -31,9 +31,9 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
   }
 }
 
-template <int ABL>
+template <int ABL, int NW = 8>
 float run(const float* qkv, float* out, int n_seq, int S, int heads, int reps, const char* what) {
-  constexpr int NW = 7, lds = 2 * (64 * 256 + 16 * (1024 + 64));
+  constexpr int lds = 2 * (64 * 256 + 16 * (1024 + 64));
   auto kern = attn_f32_blocks_kernel<NW, ABL>;
   HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipEvent_t a, b;
@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
   run<4>(qkv, out, n_seq, S, heads, reps, "no staging, no barriers");
   run<5>(qkv, out, n_seq, S, heads, reps, "no P.V MFMAs (VALU stand-in)");
   run<6>(qkv, out, n_seq, S, heads, reps, "no S MFMAs (VALU stand-in)");
+  run<0, 7>(qkv, out, n_seq, S, heads, reps, "7 waves per workgroup (14 tile slots)");
   run<0>(qkv, out, n_seq, S, heads, reps, "product kernel (again)");
   return 0;
 }
