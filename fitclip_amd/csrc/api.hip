@@ -584,6 +584,11 @@ int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, i
 int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream st) {
   return launch_convert(in, out, out_kind, n, st);
 }
+int fc_split6(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t is_weight,
+              fc_stream st) {
+  if (!in || !out) return fail(FC_EINVAL, "fc_split6: null operand");
+  return launch_split6(in, (long)ld_in, out, (long)ld_out, (long)rows, K, is_weight, st);
+}
 
 int fc_profile_enable(fc_handle* h, int32_t max_records) {
   if (!h || max_records < 0) return fail(FC_EINVAL, "fc_profile_enable: bad argument");

@@ -42,7 +42,31 @@ enum Epilogue : int {
   EPI_PATCH_F32 = 3,  // C(f32)[m + m/P + 1] = acc + pos[(m % P) + 1]   (patch embedding into the token stream)
   EPI_STORE_F32 = 4,  // C(f32) = alpha * acc (+ bias if given)
   EPI_DGELU_T = 5,    // C(T)   = acc * quickgelu'(aux(T)[m, n])   (backward of c_fc's activation; aux laid out as C)
+  EPI_BIAS_F32 = 6,   // C(f32) = acc + bias                        (bf16 six-plane operands in, fp32 out: split-fp32 mode)
+  EPI_GELU_X6 = 7,    // C(bf16 [M, 6 N]) = six_planes(quickgelu(acc + bias))   (next GEMM's six-plane A operand)
 };
+
+// ---- split-fp32 ("x6") operands.  An fp32 number is exactly the sum of three bf16 numbers, x = p1 + p2 + p3
+// (p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2), round to nearest), and a product x * y is recovered to 2^-26
+// from six bf16 products p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1.  Laid out along K - every 32 columns of an activation
+// row become the 192 bf16 [p1 p1 p2 p2 p1 p3] (32 each), of a weight row [q1 q2 q1 q2 q3 q1] - the sum of the six
+// products of every column is an ordinary bf16 dot product over 6 K columns, accumulated in fp32 by the bf16 MFMA GEMM.
+constexpr int X6_CHUNK = 32;   // columns per group
+constexpr int X6_PLANES = 6;   // bf16 copies per column
+#ifdef __HIPCC__
+// x = p1 + p2 + p3 exactly.  Contraction is switched off: hipcc would otherwise fuse `x - p1` with the multiply that
+// produced x (fma on the UNROUNDED product), and the planes would describe a number that is not the fp32 value x.
+__device__ __forceinline__ void split3(const f32x4& x, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    p1[e] = static_cast<bf16>(x[e]);
+    const float r1 = x[e] - static_cast<float>(p1[e]);
+    p2[e] = static_cast<bf16>(r1);
+    p3[e] = static_cast<bf16>(r1 - static_cast<float>(p2[e]));
+  }
+}
+#endif
 
 struct GemmArgs {
   const void* A;      // T [M, lda]
@@ -98,6 +122,8 @@ int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int f
 int launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t stream);
 int launch_group_mean(const float* in, float* out, int n_groups, int group, int dim, hipStream_t stream);
 int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream_t stream);
+// six-plane bf16 image [rows, 6 K] of fp32 rows [rows, K] (is_weight selects the weight-side plane order)
+int launch_split6(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int is_weight, hipStream_t stream);
 int launch_transpose_convert(const float* in, void* out, int out_kind, int rows, int cols, hipStream_t stream);
 int launch_wise(const float* a, const float* b, double w, float* out, size_t n, hipStream_t stream);
 

@@ -484,6 +484,43 @@ __global__ void __launch_bounds__(256) convert_kernel(const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) put<OutT>(out + n4 * 4 + threadIdx.x, in[n4 * 4 + threadIdx.x]);
 }
 
+// Six-plane bf16 image of fp32 rows (common.h, "split-fp32 operands"): every group of 32 columns becomes 192 bf16,
+// [p1 p1 p2 p2 p1 p3] for an activation (is_weight = 0) and [p1 p2 p1 p2 p3 p1] for a weight.  Thread = 4 columns.
+// A device helper the LayerNorm / attention kernels share when they write this image themselves.
+__device__ __forceinline__ void store_x6_activation(bf16* row_out, int col, const f32x4& x) {
+  bf16x4 p1, p2, p3;
+  split3(x, p1, p2, p3);
+  bf16* g = row_out + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
+  *reinterpret_cast<bf16x4*>(g) = p1;
+  *reinterpret_cast<bf16x4*>(g + X6_CHUNK) = p1;
+  *reinterpret_cast<bf16x4*>(g + 2 * X6_CHUNK) = p2;
+  *reinterpret_cast<bf16x4*>(g + 3 * X6_CHUNK) = p2;
+  *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p1;
+  *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p3;
+}
+__global__ void __launch_bounds__(256) split6_kernel(const float* __restrict__ in, long ld_in, bf16* __restrict__ out,
+                                                     long ld_out, long rows, int K, int is_weight) {
+  const long per_row = K / 4, total = rows * per_row;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / per_row;
+    const int col = (int)(i - row * per_row) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(in + row * ld_in + col);
+    if (!is_weight) {
+      store_x6_activation(out + row * ld_out, col, x);
+    } else {
+      bf16x4 p1, p2, p3;
+      split3(x, p1, p2, p3);
+      bf16* g = out + row * ld_out + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
+      *reinterpret_cast<bf16x4*>(g) = p1;
+      *reinterpret_cast<bf16x4*>(g + X6_CHUNK) = p2;
+      *reinterpret_cast<bf16x4*>(g + 2 * X6_CHUNK) = p1;
+      *reinterpret_cast<bf16x4*>(g + 3 * X6_CHUNK) = p2;
+      *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p3;
+      *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p1;
+    }
+  }
+}
+
 // out[c, r] = in[r, c]  (weight packing of visual.proj / text_projection: [K, N] -> [N, K]); tiny, run once.
 template <typename OutT>
 __global__ void __launch_bounds__(256) transpose_convert_kernel(const float* __restrict__ in, OutT* __restrict__ out,
@@ -680,6 +717,17 @@ int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream
   else
     hipLaunchKernelGGL(convert_kernel<float>, dim3(blocks), dim3(256), 0, stream, in, (float*)out, n4, n);
   FC_CHECK_LAUNCH("convert");
+  return FC_OK;
+}
+
+int launch_split6(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int is_weight, hipStream_t stream) {
+  if (rows <= 0 || K <= 0) return FC_OK;
+  if (K % X6_CHUNK || ld_in % 4 || ld_in < K || ld_out % 8 || ld_out < (long)X6_PLANES * K ||
+      (((uintptr_t)in | (uintptr_t)out) & 15))
+    return fail(FC_EINVAL, "split6: K=%d must be a multiple of 32, rows 16-byte aligned, ld_out >= 6 K", K);
+  hipLaunchKernelGGL(split6_kernel, dim3(flat_blocks((size_t)rows * (K / 4))), dim3(256), 0, stream, in, ld_in, (bf16*)out,
+                     ld_out, rows, K, is_weight);
+  FC_CHECK_LAUNCH("split6");
   return FC_OK;
 }
 

@@ -7,7 +7,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import EPI_BIAS_T, EPI_GELU_T, EPI_PATCH_F32, EPI_RESID_F32, EPI_STORE_F32, PREC_BF16, PREC_F32  # noqa
+from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X6, EPI_PATCH_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
+                   PREC_BF16, PREC_F32)
 
 _KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
 
@@ -35,12 +36,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError("inner dimensions differ")
-    f32_out = epilogue in (EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32)
+    f32_out = epilogue in (EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_BIAS_F32)
     if out is None:
         if epilogue == EPI_RESID_F32:
             raise ValueError("the residual epilogue accumulates into `out`")
         rows = M + M // patches if epilogue == EPI_PATCH_F32 else M
-        out = torch.empty((rows, N), dtype=torch.float32 if f32_out else a.dtype, device=a.device)
+        cols = 6 * N if epilogue == EPI_GELU_X6 else N  # six bf16 planes per column (split6)
+        out = torch.empty((rows, cols), dtype=torch.float32 if f32_out else a.dtype, device=a.device)
     _dev(out, "out", torch.float32 if f32_out else a.dtype)
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().fc_gemm(_KIND[a.dtype], epilogue, a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(),
@@ -91,6 +93,20 @@ def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: b
     with torch.cuda.device(qkv.device):
         _lib.check(_lib.load().fc_attention(_KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(), n_seq, seq_len, heads,
                                             int(causal), _lib.current_stream()), "fc_attention")
+    return out
+
+
+def split6(x: torch.Tensor, weight: bool = False) -> torch.Tensor:
+    """Six-plane bf16 image [rows, 6 K] of fp32 rows [rows, K] (fc_split6): x = p1 + p2 + p3 exactly; every 32 columns
+    become [p1 p1 p2 p2 p1 p3] (activations) or [p1 p2 p1 p2 p3 p1] (`weight`), so a bf16 GEMM over the 6 K columns
+    (epilogues EPI_BIAS_F32 / EPI_GELU_X6) reproduces the fp32 product."""
+    _dev(x, "x", torch.float32)
+    if x.dim() != 2 or x.shape[1] % 32:
+        raise ValueError("split6 needs [rows, K] with K a multiple of 32")
+    out = torch.empty((x.shape[0], 6 * x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().fc_split6(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                                         int(weight), _lib.current_stream()), "fc_split6")
     return out
 
 

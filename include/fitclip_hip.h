@@ -159,6 +159,13 @@ FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
+/* Split-fp32 operand image: fp32 rows [rows, K] (row stride ld_in) -> bf16 [rows, 6 K] (row stride ld_out).  x = p1 + p2 + p3
+ * exactly in three bf16 numbers; every 32 columns become [p1 p1 p2 p2 p1 p3] (activation side, is_weight = 0) or
+ * [p1 p2 p1 p2 p3 p1] (weight side), so that a bf16 GEMM over the 6 K columns accumulates the six products that recover
+ * the fp32 product to 2^-26 (fc_gemm epilogues 6 = fp32 output, 7 = QuickGELU + six-plane output).  Replaces nothing in
+ * the reference: it is how this library reproduces the reference's fp32 `F.linear` on the bf16 matrix cores. */
+FC_API int fc_split6(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t is_weight,
+              fc_stream stream);
 
 /* ---- training: the KD fine-tuning step of the student -------------------------------------------
  * Replaces autograd + torch.optim.AdamW for `TeacherStudentLightningModule.training_step / training_step_end /
