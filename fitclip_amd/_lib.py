@@ -26,7 +26,7 @@ class fc_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size", "context_length",
         "vocab_size", "transformer_width", "transformer_heads", "transformer_layers", "precision", "chunk_frames",
-        "chunk_texts", "gemm_tile", "prune_last_block")]
+        "chunk_texts", "gemm_tile", "prune_last_block", "split_gemm")]
 
 
 class fc_prof_record(C.Structure):

@@ -22,7 +22,11 @@ from . import _lib
 from .synth import ClipDims, VIT_B_16, parameter_shapes
 
 _PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
-               "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
+               "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16,
+               # fp32 results from the bf16 matrix cores: the block GEMMs of the visual tower over split-fp32 operands
+               # (three bf16 numbers per value, six bf16 products per fp32 product: fc_config.split_gemm), all else fp32
+               "fp32x6": _lib.PREC_F32}
+_SPLIT_GEMM = ("fp32x6",)
 # Opt-in: slices of a big image batch go to this many HIP streams (`CLIP._encode_image_lanes`).  4 gives ~1 % more
 # throughput at 2048 frames, but kernels of different slices then overlap in time, so per-kernel durations (the roofline
 # evidence of bench.py and rocprofv3) stop describing a kernel that owns the chip: off (1) by default.
@@ -137,7 +141,8 @@ class CLIP(nn.Module):
             cfg = _lib.fc_config(d.embed_dim, d.image_resolution, d.vision_layers, d.vision_width, d.vision_patch_size,
                                  d.context_length, d.vocab_size, d.transformer_width, d.transformer_heads,
                                  d.transformer_layers, _PRECISIONS[self.precision], self.chunk_frames,
-                                 self.chunk_texts, self.gemm_tile, int(self.prune_last_block))
+                                 self.chunk_texts, self.gemm_tile, int(self.prune_last_block),
+                                 int(self.precision in _SPLIT_GEMM))
             h = _lib._vp()
             _lib.check(lib.fc_create(cfg, h), "fc_create")
             rt.handle, rt.key = h, key
@@ -197,6 +202,8 @@ class CLIP(nn.Module):
     def _chunk_frames(self) -> int:
         if self.chunk_frames > 0:
             return self.chunk_frames
+        if self.precision in _SPLIT_GEMM:
+            return 512
         return 998 if _PRECISIONS[self.precision] == _lib.PREC_F32 else 512  # order of the library's pass size (ViT-B/16)
 
     def _encode_image_lanes(self, rt: "_Runtime", image: torch.Tensor, out: torch.Tensor, lanes: int) -> None:

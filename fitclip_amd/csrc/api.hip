@@ -99,7 +99,7 @@ size_t numel(const std::vector<int64_t>& s) {
 }
 
 // GEMM weights that get a kernel-layout copy
-enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS };
+enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS, PACK_SPLIT6 };
 struct PackItem {
   std::string name;
   PackMode mode;
@@ -122,12 +122,20 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
     blocks("visual.transformer", h->cfg.vision_layers);
     blocks("transformer", h->cfg.transformer_layers);
   }
+  if (h->split()) {  // six-plane bf16 images of the visual tower's block weights (the fp32 tensors stay in use as well)
+    for (int i = 0; i < h->cfg.vision_layers; ++i) {
+      const std::string b = "visual.transformer.resblocks." + std::to_string(i);
+      for (const char* n : {".attn.in_proj_weight", ".attn.out_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight"})
+        l.push_back({b + n, PACK_SPLIT6});
+    }
+  }
   l.push_back({"visual.proj", PACK_TRANSPOSE});
   l.push_back({"text_projection", PACK_TRANSPOSE});
   return l;
 }
 size_t packed_item_bytes(const fc_handle* h, const PackItem& e) {
   const auto& shape = h->slots.at(e.name).shape;
+  if (e.mode == PACK_SPLIT6) return align_up(numel(shape) * X6_PLANES * 2);
   const size_t n = e.mode == PACK_PAD_ROWS ? (size_t)shape[0] * h->patch_kp() : numel(shape);
   return align_up(n * h->esz);
 }
@@ -179,26 +187,33 @@ struct Scratch {
   float* x;
   char* xn;
   char* big;
+  float* d;   // split mode only: fp32 [M, w] projection deltas (out_proj, c_proj)
   char* clsn;
   int* eot;
   size_t total;
 };
 
-// workspace carve for `c` items of `tokens` tokens and width `w` (base may be null: sizes only)
-Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols) {
+// workspace carve for `c` items of `tokens` tokens and width `w` (base may be null: sizes only).  `split`: the layout
+// of the split-fp32 visual tower - xn holds six-plane rows (12 w bytes), big the fp32 QKV rows or the six-plane MLP
+// hidden rows (48 w bytes), d the fp32 deltas; it contains the plain fp32 layout, which small passes fall back to.
+Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, bool split = false) {
   Scratch s{};
   const size_t M = (size_t)c * tokens;
   const size_t big_cols = (size_t)std::max(4 * w, min_big_cols);
+  const size_t xn_row = split ? (size_t)w * X6_PLANES * 2 : (size_t)w * esz;
+  const size_t big_row = split ? std::max(big_cols * esz, (size_t)4 * w * X6_PLANES * 2) : big_cols * esz;
   const size_t o_x = 0;
   const size_t o_xn = o_x + align_up(M * w * 4);
-  const size_t o_big = o_xn + align_up(M * w * esz);
-  const size_t o_cls = o_big + align_up(M * big_cols * esz);
+  const size_t o_big = o_xn + align_up(M * xn_row);
+  const size_t o_d = o_big + align_up(M * big_row);
+  const size_t o_cls = o_d + (split ? align_up(M * w * 4) : 0);
   const size_t o_eot = o_cls + align_up((size_t)c * w * esz);
   s.total = o_eot + align_up((size_t)c * 4);
   if (base) {
     s.x = reinterpret_cast<float*>(base + o_x);
     s.xn = base + o_xn;
     s.big = base + o_big;
+    s.d = split ? reinterpret_cast<float*>(base + o_d) : nullptr;
     s.clsn = base + o_cls;
     s.eot = reinterpret_cast<int*>(base + o_eot);
   }
@@ -268,6 +283,70 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
   return launch_add_layernorm(s.x, xs_pool, s.xn, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 0, st);
 }
 
+// ---- split-fp32 visual tower (cfg.split_gemm): the same block sequence with the four big GEMMs on the bf16 matrix
+// cores over six-plane operands (common.h).  Producers write the six-plane image directly: LayerNorm (KIND_X6), the
+// fp32 attention kernel, c_fc's QuickGELU epilogue (EPI_GELU_X6); QKV / out_proj / c_proj return fp32 (EPI_BIAS_F32).
+// Everything else - residual stream, LayerNorm statistics, softmax - is the fp32 path's code.
+int gemm_x6(fc_handle* h, int epi, const void* A6, const void* W6, const float* bias, void* C, int M, int N, int K,
+            int ldc, hipStream_t st) {
+  GemmArgs a{};
+  a.A = A6; a.W = W6; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
+  a.M = M; a.N = N; a.K = X6_PLANES * K; a.lda = a.K; a.ldw = a.K; a.ldc = ldc; a.P = 0;
+  ProfScope ps(h, st, PREC_BF16, epi, 3, a);
+  return launch_gemm(PREC_BF16, epi, a, 0, st);
+}
+
+// can every block GEMM of a pass of M rows run on the pipelined kernel (enough tiles, 32-bit operand offsets)?
+bool x6_pass_ok(int M, int w) {
+  const int shapes[4][2] = {{3 * w, w}, {w, w}, {4 * w, w}, {w, 4 * w}};
+  for (auto& sh : shapes) {
+    GemmArgs a{};
+    a.M = M; a.N = sh[0]; a.K = X6_PLANES * sh[1]; a.lda = a.K; a.ldw = a.K;
+    a.ldc = sh[0] == 4 * w ? X6_PLANES * sh[0] : sh[0];
+    static const float kBias = 0.f;
+    a.bias = reinterpret_cast<const float*>((uintptr_t)&kBias & ~(uintptr_t)15);  // only its alignment is inspected
+    if (gemm_resolved_tile(PREC_BF16, EPI_BIAS_F32, a, 0) != 3) return false;
+  }
+  return true;
+}
+
+int run_blocks_x6(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,
+                  const float* fin_b, long pool_step, hipStream_t st, const TowerEntry& entry) {
+  const int M = n_seq * S;
+  const long ld6 = (long)X6_PLANES * w;
+  const size_t nl = t.blocks.size();
+  for (size_t l = 0; l < nl; ++l) {
+    const Block& b = t.blocks[l];
+    if (l == 0) {
+      FC_TRY(launch_layernorm_pair(s.x, entry.cls, entry.pos0, S, entry.pre_w, entry.pre_b, b.ln1_w, b.ln1_b, s.xn,
+                                   KIND_X6, M, w, st));
+    } else {
+      ProfScope ps(h, st, 2, M, w, 1);
+      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld6, KIND_X6, M, w, 1, 0, st));
+    }
+    FC_TRY(gemm_x6(h, EPI_BIAS_F32, s.xn, b.in_w6, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
+    {
+      ProfScope ps(h, st, 1, n_seq, heads, S);
+      if (attention_x6_supported(S, 0)) {
+        FC_TRY(launch_attention_x6(s.big, s.xn, n_seq, S, heads, st));
+      } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
+        FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
+        FC_TRY(launch_split6(s.d, w, s.xn, ld6, M, w, 0, st));
+      }
+    }
+    FC_TRY(gemm_x6(h, EPI_BIAS_F32, s.xn, b.out_w6, b.out_b, s.d, M, w, w, w, st));
+    {
+      ProfScope ps(h, st, 2, M, w, 1);
+      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld6, KIND_X6, M, w, 1, 0, st));
+    }
+    FC_TRY(gemm_x6(h, EPI_GELU_X6, s.xn, b.fc_w6, b.fc_b, s.big, M, 4 * w, w, X6_PLANES * 4 * w, st));
+    FC_TRY(gemm_x6(h, EPI_BIAS_F32, s.big, b.proj_w6, b.proj_b, s.d, M, w, 4 * w, w, st));
+  }
+  // the last c_proj delta is still pending in s.d: fold it into the final LayerNorm of the pooled rows
+  const long xs_pool = pool_step * w;
+  return launch_add_layernorm(s.x, xs_pool, s.d, xs_pool, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, 0, 0, st);
+}
+
 int device_cus() {
   static int cus = 0;
   if (!cus) {
@@ -293,6 +372,11 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
   if (c.precision != FC_PREC_F32) return 512;
+  if (h->split()) {  // bf16-pipe GEMMs: no whole-round planning (as in bf16 mode); the six-plane MLP rows of a pass (48 w
+    // bytes each) must stay below the 4 GiB of the kernel's 32-bit operand offsets
+    const long max6 = (long)(((1LL << 32) - 1) / (8LL * c.vision_width * X6_PLANES) / h->vtokens());
+    return (int)std::max(1L, std::min(512L, max6));
+  }
   const long T = h->vtokens(), w = c.vision_width, cus = device_cus();
   const long max_frames = std::max(1L, (long)((1LL << 32) - 1) / (16 * w) / T);  // 32-bit operand offsets of the 4w-wide buffer
   auto rounds = [&](long frames) {  // tile rounds x K-steps of the four block GEMMs of one pass
@@ -315,7 +399,7 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
 
 size_t per_item_bytes(const fc_handle* h, int tower) {
   const fc_config& c = h->cfg;
-  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_kp()).total;
+  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_kp(), h->split()).total;
   return carve(nullptr, 1, c.context_length, c.transformer_width, h->esz, 0).total;
 }
 
@@ -333,6 +417,8 @@ int fc_create(const fc_config* cfg, fc_handle** out) {
   if (!cfg || !out) return fail(FC_EINVAL, "fc_create: null argument");
   const fc_config& c = *cfg;
   if (c.precision != FC_PREC_F32 && c.precision != FC_PREC_BF16) return fail(FC_EINVAL, "fc_create: precision");
+  if (c.split_gemm && (c.precision != FC_PREC_F32 || c.vision_width % 256 || c.prune_last_block))
+    return fail(FC_EINVAL, "fc_create: split_gemm needs the fp32 precision, a vision width that is a multiple of 256 and prune_last_block = 0");
   if (c.vision_width % 64 || c.transformer_width % 64 || c.vision_width <= 0 || c.transformer_width <= 0)
     return fail(FC_EINVAL, "fc_create: widths must be positive multiples of 64 (head dim 64)");
   if (c.transformer_heads * 64 != c.transformer_width)
@@ -403,6 +489,12 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       FC_TRY(launch_transpose_convert(slot.ptr, dst, kind, (int)slot.shape[0], (int)slot.shape[1], stream));
     } else if (e.mode == PACK_PAD_ROWS) {
       FC_TRY(launch_convert_rows(slot.ptr, dst, kind, (long)slot.shape[0], h->patch_k(), h->patch_kp(), stream));
+    } else if (e.mode == PACK_SPLIT6) {
+      FC_TRY(launch_split6(slot.ptr, (long)slot.shape[1], dst, (long)slot.shape[1] * X6_PLANES, (long)slot.shape[0],
+                           (int)slot.shape[1], 1, stream));
+      packed[e.name + "#x6"] = dst;
+      off += packed_item_bytes(h, e);
+      continue;
     } else {
       FC_TRY(launch_convert(slot.ptr, dst, kind, numel(slot.shape), stream));
     }
@@ -424,6 +516,12 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       k.fc_b = h->w(b + ".mlp.c_fc.bias"); k.proj_b = h->w(b + ".mlp.c_proj.bias");
       k.in_w = gw(b + ".attn.in_proj_weight"); k.out_w = gw(b + ".attn.out_proj.weight");
       k.fc_w = gw(b + ".mlp.c_fc.weight"); k.proj_w = gw(b + ".mlp.c_proj.weight");
+      auto x6 = [&](const char* n) -> const void* {
+        auto it = packed.find(b + n + "#x6");
+        return it != packed.end() ? it->second : nullptr;
+      };
+      k.in_w6 = x6(".attn.in_proj_weight"); k.out_w6 = x6(".attn.out_proj.weight");
+      k.fc_w6 = x6(".mlp.c_fc.weight"); k.proj_w6 = x6(".mlp.c_proj.weight");
     }
   };
   fill(h->vis, "visual.transformer", h->cfg.vision_layers);
@@ -440,7 +538,7 @@ size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n) {
   if (!h || n <= 0 || tower < 0 || tower > 1) return 0;
   const int c = std::min(n, planned_chunk(h, tower, n));
   const fc_config& k = h->cfg;
-  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp()).total
+  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp(), h->split()).total
                     : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0).total;
 }
 
@@ -455,15 +553,16 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
   const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_kp();
   const size_t per = per_item_bytes(h, 0);
   int chunk = std::min(n, planned_chunk(h, 0, n));
-  if (carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) {  // smaller workspace: as many items as fit
+  const bool split = h->split();
+  if (carve(nullptr, chunk, T, vw, h->esz, Kp, split).total > ws_bytes) {  // smaller workspace: as many items as fit
     chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
-    while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp).total > ws_bytes) --chunk;
+    while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp, split).total > ws_bytes) --chunk;
   }
   if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_image: workspace too small (need >= %zu bytes)", per + 2048);
   const int kind = c.precision;
   for (int off = 0; off < n; off += chunk) {
     const int cn = std::min(chunk, n - off);
-    const Scratch s = carve(static_cast<char*>(ws), cn, T, vw, h->esz, Kp);
+    const Scratch s = carve(static_cast<char*>(ws), cn, T, vw, h->esz, Kp, split);
     const float* f = frames + (size_t)off * 3 * R * R;
     const int p = c.vision_patch_size;
     if (kind == PREC_F32 && Kp == h->patch_k() && p % 4 == 0 && R % 4 == 0) {
@@ -481,8 +580,13 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     }
     const TowerEntry entry{h->w("visual.class_embedding"), h->w("visual.positional_embedding"),
                            h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias")};
-    FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),
-                      h->w("visual.ln_post.bias"), nullptr, T, st, &entry));
+    if (split && x6_pass_ok(cn * T, vw)) {
+      FC_TRY(run_blocks_x6(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
+                           h->w("visual.ln_post.bias"), T, st, entry));
+    } else {  // (split mode: a pass too small for the pipelined GEMM takes the plain fp32 path)
+      FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),
+                        h->w("visual.ln_post.bias"), nullptr, T, st, &entry));
+    }
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }

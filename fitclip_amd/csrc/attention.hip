@@ -667,7 +667,8 @@ __device__ __forceinline__ float exp_neg_finite_f32(float x) {
   const float e = __builtin_amdgcn_exp2f(t);
   return __builtin_fmaf(e, r * 0.6931471805599453f, e);
 }
-template <int NW, int ABL = 0>
+// X6: `out` is the six-plane bf16 image [rows, 6 D] of the fp32 result (split-fp32 mode: out_proj's A operand).
+template <int NW, int ABL = 0, bool X6 = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4)))  // <= 128 VGPRs: two workgroups per CU
 attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads) {
   constexpr int BT = 4, BK = BT * 16;          // key tiles / keys per block
@@ -809,9 +810,26 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
     const int query = qtile[qi] * 16 + r;
     const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
     if (query < S) {
-      float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
+      if constexpr (X6) {
+        bf16* orow = reinterpret_cast<bf16*>(out) + ((long)seq * S + query) * (X6_PLANES * D);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[qi][n] * inv;
+        for (int n = 0; n < 4; ++n) {
+          const int col = h * 64 + 16 * n + 4 * g;
+          bf16x4 p1, p2, p3;
+          split3(o[qi][n] * inv, p1, p2, p3);
+          bf16* gp = orow + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
+          *reinterpret_cast<bf16x4*>(gp) = p1;
+          *reinterpret_cast<bf16x4*>(gp + X6_CHUNK) = p1;
+          *reinterpret_cast<bf16x4*>(gp + 2 * X6_CHUNK) = p2;
+          *reinterpret_cast<bf16x4*>(gp + 3 * X6_CHUNK) = p2;
+          *reinterpret_cast<bf16x4*>(gp + 4 * X6_CHUNK) = p1;
+          *reinterpret_cast<bf16x4*>(gp + 5 * X6_CHUNK) = p3;
+        }
+      } else {
+        float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[qi][n] * inv;
+      }
     }
   }
 }
@@ -949,10 +967,14 @@ int launch_f32_mfma(const void* qkv, void* out, int n_seq, int S, int heads, hip
   return FC_OK;
 }
 
-int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st) {
+int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st, bool x6 = false) {
   constexpr int NW = 8, lds = 2 * (64 * 256 + 16 * (1024 + 64));  // two 33 KiB buffers (64 keys of K and V): two workgroups per CU
-  hipLaunchKernelGGL((attn_f32_blocks_kernel<NW>), dim3(n_seq * heads), dim3(NW * 64), lds, st, (const float*)qkv,
-                     (float*)out, S, heads);
+  if (x6)
+    hipLaunchKernelGGL((attn_f32_blocks_kernel<NW, 0, true>), dim3(n_seq * heads), dim3(NW * 64), lds, st,
+                       (const float*)qkv, (float*)out, S, heads);
+  else
+    hipLaunchKernelGGL((attn_f32_blocks_kernel<NW>), dim3(n_seq * heads), dim3(NW * 64), lds, st, (const float*)qkv,
+                       (float*)out, S, heads);
   FC_CHECK_LAUNCH("attention(f32 blocks)");
   return FC_OK;
 }
@@ -971,6 +993,17 @@ int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int cau
 }
 
 }  // namespace
+
+// fp32 attention whose output is the six-plane bf16 image [n_seq * S, 6 * heads * 64] (split-fp32 mode).  Only the
+// streaming-block kernel writes it directly (the ViT's 197 tokens); `attention_x6_supported` tells the caller when to
+// run the plain fp32 kernel + fc_split6 instead.
+bool attention_x6_supported(int S, int causal) { return !causal && S > 112 && S <= 224; }
+int launch_attention_x6(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream) {
+  if (n_seq <= 0) return FC_OK;
+  if (!attention_x6_supported(S, 0) || heads <= 0) return fail(FC_EINVAL, "attention(x6): S=%d heads=%d", S, heads);
+  if (((uintptr_t)qkv | (uintptr_t)out) & 15) return fail(FC_EINVAL, "attention(x6): unaligned operand");
+  return launch_f32_blocks(qkv, out, n_seq, S, heads, stream, true);
+}
 
 int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S, int heads, int causal,
                      hipStream_t stream) {

@@ -51,6 +51,7 @@ enum Epilogue : int {
 // from six bf16 products p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1.  Laid out along K - every 32 columns of an activation
 // row become the 192 bf16 [p1 p1 p2 p2 p1 p3] (32 each), of a weight row [q1 q2 q1 q2 q3 q1] - the sum of the six
 // products of every column is an ordinary bf16 dot product over 6 K columns, accumulated in fp32 by the bf16 MFMA GEMM.
+constexpr int KIND_X6 = 2;     // element-kind argument of the row kernels: output = six-plane bf16 rows (0 = f32, 1 = bf16)
 constexpr int X6_CHUNK = 32;   // columns per group
 constexpr int X6_PLANES = 6;   // bf16 copies per column
 #ifdef __HIPCC__
@@ -94,6 +95,8 @@ int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile)
 // qkv: T [n_seq * S, 3 * D] (q | k | v, heads of 64 inside each), out: T [n_seq * S, D]
 int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S, int heads, int causal,
                      hipStream_t stream);
+bool attention_x6_supported(int S, int causal);
+int launch_attention_x6(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream);
 
 // --------------------------------------------------------------------------------------------- row ops
 // y[i] = LN(x[row(i)]) * gamma + beta.  row(i) = gather ? gather[i] : i; x row r at x + r * x_stride.

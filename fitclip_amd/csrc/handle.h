@@ -18,6 +18,8 @@ struct WeightSlot {
 struct Block {
   const float *ln1_w, *ln1_b, *in_b, *out_b, *ln2_w, *ln2_b, *fc_b, *proj_b;
   const void *in_w, *out_w, *fc_w, *proj_w;  // element type T of the handle's precision, [N, K]
+  // split_gemm: six-plane bf16 images [N, 6 K] of the four weights (visual tower only)
+  const void *in_w6 = nullptr, *out_w6 = nullptr, *fc_w6 = nullptr, *proj_w6 = nullptr;
   // training: transposed copies [K, N] for the dgrad GEMMs (fc_train_prepare)
   const void *in_wT = nullptr, *out_wT = nullptr, *fc_wT = nullptr, *proj_wT = nullptr;
 };
@@ -57,6 +59,7 @@ struct fc_handle {
     const int gran = cfg.precision == FC_PREC_BF16 ? 64 : 32;
     return (patch_k() + gran - 1) / gran * gran;
   }
+  bool split() const { return cfg.precision == FC_PREC_F32 && cfg.split_gemm != 0; }
   const float* w(const std::string& n) const { return slots.at(n).ptr; }
   float* grad(const std::string& n) const { return slots.at(n).grad; }
 };

@@ -1,6 +1,8 @@
 // HBM-bound row kernels around the GEMMs: LayerNorm, patch extraction, embeddings, pooling, conversions, WiSE.
 // All are one-wave-per-row or flat grid-stride kernels with 16-byte accesses (guide: Appendix B, Guideline 13).
 #include "common.h"
+
+#include <type_traits>
 #include <climits>
 #include <cmath>
 
@@ -22,6 +24,28 @@ template <> __device__ __forceinline__ void put4<bf16>(bf16* p, const f32x4& v) 
   o[2] = static_cast<bf16>(v[2]); o[3] = static_cast<bf16>(v[3]);
   *reinterpret_cast<bf16x4*>(p) = o;
 }
+
+// Output kind "x6": a row of 6 D bf16, the six-plane image of D fp32 values (common.h, split-fp32 operands).  x6_t is a
+// 2-byte stand-in element so that row pointers and strides count bf16 elements.
+struct x6_t { bf16 v; };
+__device__ __forceinline__ void store_x6_activation(bf16* row_out, int col, const f32x4& x) {
+  bf16x4 p1, p2, p3;
+  split3(x, p1, p2, p3);
+  bf16* g = row_out + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
+  *reinterpret_cast<bf16x4*>(g) = p1;
+  *reinterpret_cast<bf16x4*>(g + X6_CHUNK) = p1;
+  *reinterpret_cast<bf16x4*>(g + 2 * X6_CHUNK) = p2;
+  *reinterpret_cast<bf16x4*>(g + 3 * X6_CHUNK) = p2;
+  *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p1;
+  *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p3;
+}
+// 4 columns starting at column c of an output row
+template <typename OutT> __device__ __forceinline__ void put4_at(OutT* row, int c, const f32x4& v) { put4<OutT>(row + c, v); }
+template <> __device__ __forceinline__ void put4_at<x6_t>(x6_t* row, int c, const f32x4& v) {
+  store_x6_activation(reinterpret_cast<bf16*>(row), c, v);
+}
+template <typename OutT> constexpr int kOutCols = 1;       // output elements per input column
+template <> constexpr int kOutCols<x6_t> = X6_PLANES;
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // One wave per row, the row lives in registers (D / 64 floats per lane), two-pass mean / centred variance in fp32
@@ -77,12 +101,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * g4[e] + b4[e];
-      put4<OutT>(yr + c, o);
+      put4_at<OutT>(yr, c, o);
     }
+    if constexpr (REM > 0) {
 #pragma unroll
-    for (int i = 0; i < REM; ++i) {
-      const int c = V4 * 256 + i * 64 + lane;
-      put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+      for (int i = 0; i < REM; ++i) {
+        const int c = V4 * 256 + i * 64 + lane;
+        if constexpr (!std::is_same_v<OutT, x6_t>) put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+      }
     }
   }
 }
@@ -150,14 +176,14 @@ __global__ void __launch_bounds__(256) layernorm_pair_kernel(float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] * rstd * g4[e] + b4[e];
         if (pass == 0) *reinterpret_cast<f32x4*>(xr + c) = v[i];
-        else put4<OutT>(y + (long)row * D + c, v[i]);
+        else put4_at<OutT>(y + (long)row * (D * kOutCols<OutT>), c, v[i]);
       }
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
         const int c = V4 * 256 + i * 64 + lane;
         s[i] = s[i] * rstd * gamma[c] + beta[c];
         if (pass == 0) xr[c] = s[i];
-        else put<OutT>(y + (long)row * D + c, s[i]);
+        else if constexpr (!std::is_same_v<OutT, x6_t>) put<OutT>(y + (long)row * D + c, s[i]);
       }
     }
   }
@@ -166,12 +192,12 @@ __global__ void __launch_bounds__(256) layernorm_pair_kernel(float* __restrict__
 // Fused residual add + LayerNorm:  v = x[r] + delta[r];  (x[r] = v);  y[i] = LN(v).  `delta` is the projection output
 // a GEMM just wrote (element type T, as y), so the residual update costs no extra pass over the fp32 stream and the
 // GEMM epilogue stays a pure store (reference: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x)), slip.py:382-385).
-template <int D, typename T>
+template <int D, typename T, typename YT = T>
 __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ x, long x_stride,
                                                             const T* __restrict__ delta, long d_stride,
                                                             const int* __restrict__ gather,
                                                             const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            const float* __restrict__ beta, YT* __restrict__ y,
                                                             long y_stride, int rows, int write_x,
                                                             int delta_compact, float* __restrict__ x_out) {
   static_assert(D % 256 == 0 || D == 128, "width");
@@ -223,7 +249,7 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
       sq += s[i] * s[i];
     }
     const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / D) + 1e-5f);
-    T* yr = y + (long)row * y_stride;
+    YT* yr = y + (long)row * y_stride;
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
       const int c = i * 256 + lane * 4;
@@ -232,31 +258,36 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * g4[e] + b4[e];
-      put4<T>(yr + c, o);
+      put4_at<YT>(yr, c, o);
     }
+    if constexpr (REM > 0) {
 #pragma unroll
-    for (int i = 0; i < REM; ++i) {
-      const int c = V4 * 256 + i * 64 + lane;
-      put<T>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+      for (int i = 0; i < REM; ++i) {
+        const int c = V4 * 256 + i * 64 + lane;
+        if constexpr (!std::is_same_v<YT, x6_t>) put<YT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+      }
     }
   }
 }
 
-template <typename T>
+template <typename T, typename YT = T>
 int add_layernorm_dispatch(float* x, long xs, const void* delta, long ds, const int* gather, const float* g,
                            const float* b, void* y, long ys, int rows, int D, int write_x, int delta_compact,
                            float* x_out, hipStream_t st) {
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   const T* dl = reinterpret_cast<const T*>(delta);
-  T* yo = reinterpret_cast<T*>(y);
+  YT* yo = reinterpret_cast<YT*>(y);
+  constexpr bool kX6 = std::is_same_v<YT, x6_t>;
+#define FC_ADDLN(W) hipLaunchKernelGGL((add_layernorm_kernel<W, T, YT>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out)
   switch (D) {
-    case 128: hipLaunchKernelGGL((add_layernorm_kernel<128, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
-    case 256: hipLaunchKernelGGL((add_layernorm_kernel<256, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
-    case 512: hipLaunchKernelGGL((add_layernorm_kernel<512, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
-    case 768: hipLaunchKernelGGL((add_layernorm_kernel<768, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
-    case 1024: hipLaunchKernelGGL((add_layernorm_kernel<1024, T>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out); break;
+    case 128: if constexpr (kX6) return fail(FC_EINVAL, "add_layernorm: six-plane output needs a width that is a multiple of 256"); else FC_ADDLN(128); break;
+    case 256: FC_ADDLN(256); break;
+    case 512: FC_ADDLN(512); break;
+    case 768: FC_ADDLN(768); break;
+    case 1024: FC_ADDLN(1024); break;
     default: return fail(FC_EINVAL, "add_layernorm: unsupported width %d", D);
   }
+#undef FC_ADDLN
   FC_CHECK_LAUNCH("add_layernorm");
   return FC_OK;
 }
@@ -267,7 +298,10 @@ int layernorm_dispatch(const float* x, long xs, const int* gather, const float* 
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   OutT* yo = reinterpret_cast<OutT*>(y);
   switch (D) {
-    case 128: hipLaunchKernelGGL((layernorm_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
+    case 128:
+      if constexpr (std::is_same_v<OutT, x6_t>) return fail(FC_EINVAL, "layernorm: six-plane output needs a width that is a multiple of 256");
+      else hipLaunchKernelGGL((layernorm_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows);
+      break;
     case 256: hipLaunchKernelGGL((layernorm_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
     case 512: hipLaunchKernelGGL((layernorm_kernel<512, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
     case 768: hipLaunchKernelGGL((layernorm_kernel<768, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
@@ -487,17 +521,6 @@ __global__ void __launch_bounds__(256) convert_kernel(const float* __restrict__ 
 // Six-plane bf16 image of fp32 rows (common.h, "split-fp32 operands"): every group of 32 columns becomes 192 bf16,
 // [p1 p1 p2 p2 p1 p3] for an activation (is_weight = 0) and [p1 p2 p1 p2 p3 p1] for a weight.  Thread = 4 columns.
 // A device helper the LayerNorm / attention kernels share when they write this image themselves.
-__device__ __forceinline__ void store_x6_activation(bf16* row_out, int col, const f32x4& x) {
-  bf16x4 p1, p2, p3;
-  split3(x, p1, p2, p3);
-  bf16* g = row_out + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
-  *reinterpret_cast<bf16x4*>(g) = p1;
-  *reinterpret_cast<bf16x4*>(g + X6_CHUNK) = p1;
-  *reinterpret_cast<bf16x4*>(g + 2 * X6_CHUNK) = p2;
-  *reinterpret_cast<bf16x4*>(g + 3 * X6_CHUNK) = p2;
-  *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p1;
-  *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p3;
-}
 __global__ void __launch_bounds__(256) split6_kernel(const float* __restrict__ in, long ld_in, bf16* __restrict__ out,
                                                      long ld_out, long rows, int K, int is_weight) {
   const long per_row = K / 4, total = rows * per_row;
@@ -570,6 +593,7 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
   if (rows <= 0) return FC_OK;
   if ((x_stride % 4) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
     return fail(FC_EINVAL, "layernorm: operands must be 16-byte aligned");
+  if (out_kind == KIND_X6) return layernorm_dispatch<x6_t>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
   return out_kind == 1 ? layernorm_dispatch<bf16>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream)
                        : layernorm_dispatch<float>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
 }
@@ -580,7 +604,10 @@ int layernorm_pair_dispatch(float* x, const float* cls, const float* pos0, int t
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   OutT* yo = reinterpret_cast<OutT*>(y);
   switch (D) {
-    case 128: hipLaunchKernelGGL((layernorm_pair_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
+    case 128:
+      if constexpr (std::is_same_v<OutT, x6_t>) return fail(FC_EINVAL, "layernorm_pair: six-plane output needs a width that is a multiple of 256");
+      else hipLaunchKernelGGL((layernorm_pair_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows);
+      break;
     case 256: hipLaunchKernelGGL((layernorm_pair_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
     case 512: hipLaunchKernelGGL((layernorm_pair_kernel<512, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
     case 768: hipLaunchKernelGGL((layernorm_pair_kernel<768, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
@@ -599,6 +626,7 @@ int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tok
       (((uintptr_t)x | (uintptr_t)cls | (uintptr_t)pos0 | (uintptr_t)g0 | (uintptr_t)b0 | (uintptr_t)g1 | (uintptr_t)b1 |
         (uintptr_t)y) & 15))
     return fail(FC_EINVAL, "layernorm_pair: operands must be 16-byte aligned");
+  if (out_kind == KIND_X6) return layernorm_pair_dispatch<x6_t>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
   return out_kind == 1 ? layernorm_pair_dispatch<bf16>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream)
                        : layernorm_pair_dispatch<float>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
 }
@@ -607,6 +635,13 @@ int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stri
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
                          int write_x, int delta_compact, hipStream_t stream, float* x_out) {
   if (rows <= 0) return FC_OK;
+  if (kind == KIND_X6) {  // delta fp32 (a split-fp32 GEMM's output), y the six-plane image of the LayerNorm output
+    if ((x_stride % 4) || (d_stride % 4) || (y_stride % 8) || y_stride < (long)X6_PLANES * D ||
+        (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta | (uintptr_t)x_out) & 15))
+      return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned");
+    return add_layernorm_dispatch<float, x6_t>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows, D,
+                                               write_x, delta_compact, x_out, stream);
+  }
   const int esz = kind == 1 ? 2 : 4;
   if ((x_stride % 4) || (d_stride * esz) % 8 || (y_stride * esz) % 8 ||
       (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta) & 15))

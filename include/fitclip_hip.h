@@ -66,6 +66,12 @@ typedef struct {
   int32_t prune_last_block;   /* 1: after the attention of the LAST block only the pooled rows (CLS / EOT) go through
                                  out_proj, LayerNorm 2 and the MLP - nothing else is read afterwards; identical
                                  embeddings, 6 % fewer FLOPs.  0 (default): every row, as the reference computes it */
+  int32_t split_gemm;         /* fp32 precision only.  1: the four block GEMMs of the VISUAL tower run on the bf16 matrix
+                                 cores over split-fp32 ("six-plane") operands - every fp32 value as three bf16 numbers,
+                                 every product as six bf16 products accumulated in fp32 (fc_split6) - at fp32 accuracy
+                                 and ~1.5x the fp32-MFMA rate; LayerNorm, attention, residual stream, patch embedding,
+                                 the text tower and passes too small for the pipelined GEMM stay on the plain fp32
+                                 path.  0 (default): fp32-input MFMA everywhere */
 } fc_config;
 
 typedef struct fc_handle fc_handle;
