@@ -683,6 +683,10 @@ int fc_add_layernorm(float* x, int64_t xs, const void* delta, int64_t ds, const 
 }
 int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream st) {
+  if (precision == KIND_X6) {  // fp32 in, six-plane bf16 out (the sequence lengths the streaming-block kernel serves)
+    if (causal) return fail(FC_EINVAL, "fc_attention: the six-plane output is not available for causal attention");
+    return launch_attention_x6(qkv, out, n_seq, S, heads, st);
+  }
   return launch_attention(precision, qkv, out, n_seq, S, heads, causal, st);
 }
 int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream st) {

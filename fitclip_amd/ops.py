@@ -11,6 +11,7 @@ from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X6, EPI_PATCH_
                    PREC_BF16, PREC_F32)
 
 _KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
+KIND_X6 = 2  # element-kind argument of the row kernels / attention: six-plane bf16 output (csrc/common.h)
 
 
 def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -62,37 +63,43 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
         rows = gather.numel()
     elif rows is None:
         rows = x.numel() // row_stride
-    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    six = out_dtype == "x6"  # six-plane bf16 rows (split6 layout)
+    y = torch.empty((rows, 6 * D if six else D), dtype=torch.bfloat16 if six else out_dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().fc_layernorm(x.data_ptr(), row_stride, _ptr(gather), gamma.data_ptr(), beta.data_ptr(),
-                                            y.data_ptr(), D, _KIND[out_dtype], rows, D, _lib.current_stream()),
-                   "fc_layernorm")
+                                            y.data_ptr(), y.shape[1], KIND_X6 if six else _KIND[out_dtype], rows, D,
+                                            _lib.current_stream()), "fc_layernorm")
     return y
 
 
 def add_layernorm(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                  write_x: bool = True) -> torch.Tensor:
-    """x += delta (in place, if write_x); returns LayerNorm(x + delta) in delta's dtype."""
-    _dev(x, "x", torch.float32), _dev(delta, "delta"), _dev(gamma, "gamma", torch.float32)
+                  write_x: bool = True, six_plane: bool = False) -> torch.Tensor:
+    """x += delta (in place, if write_x); returns LayerNorm(x + delta) in delta's dtype, or (`six_plane`, fp32 delta) as
+    six-plane bf16 rows [rows, 6 D] (split6 layout)."""
+    _dev(x, "x", torch.float32), _dev(delta, "delta", torch.float32 if six_plane else None), _dev(gamma, "gamma", torch.float32)
     rows, D = x.shape
-    y = torch.empty((rows, D), dtype=delta.dtype, device=x.device)
+    y = torch.empty((rows, 6 * D if six_plane else D), dtype=torch.bfloat16 if six_plane else delta.dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().fc_add_layernorm(x.data_ptr(), D, delta.data_ptr(), D, None, gamma.data_ptr(),
-                                                beta.data_ptr(), y.data_ptr(), D, _KIND[delta.dtype], rows, D,
+                                                beta.data_ptr(), y.data_ptr(), y.shape[1],
+                                                KIND_X6 if six_plane else _KIND[delta.dtype], rows, D,
                                                 int(write_x), _lib.current_stream()), "fc_add_layernorm")
     return y
 
 
-def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False) -> torch.Tensor:
-    """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]."""
-    _dev(qkv, "qkv")
+def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False,
+              six_plane: bool = False) -> torch.Tensor:
+    """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]; `six_plane`
+    (float32 qkv, non-causal, 113..224 tokens): six-plane bf16 rows [.., 6 * heads * 64] of the fp32 result."""
+    _dev(qkv, "qkv", torch.float32 if six_plane else None)
     D = heads * 64
     if qkv.shape != (n_seq * seq_len, 3 * D):
         raise ValueError(f"qkv shape {tuple(qkv.shape)} != {(n_seq * seq_len, 3 * D)}")
-    out = torch.empty((n_seq * seq_len, D), dtype=qkv.dtype, device=qkv.device)
+    out = torch.empty((n_seq * seq_len, 6 * D if six_plane else D), dtype=torch.bfloat16 if six_plane else qkv.dtype,
+                      device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().fc_attention(_KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(), n_seq, seq_len, heads,
-                                            int(causal), _lib.current_stream()), "fc_attention")
+        _lib.check(_lib.load().fc_attention(KIND_X6 if six_plane else _KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(),
+                                            n_seq, seq_len, heads, int(causal), _lib.current_stream()), "fc_attention")
     return out
 
 

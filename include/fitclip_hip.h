@@ -155,13 +155,14 @@ FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather,
                  void* y, int64_t y_stride, int32_t out_kind, int32_t rows, int32_t D, fc_stream stream);
 /* v = x[r] + delta[r]; if write_x: x[r] = v; y[i] = LayerNorm(v) * gamma + beta, r = gather ? gather[i] : i.  The
  * residual update of a pre-LN block (slip.py:382-385) folded into the LayerNorm that follows it.  delta and y have
- * element kind `kind`. */
+ * element kind `kind`; kind 2: delta fp32, y six-plane bf16 rows (fc_split6 layout, y_stride >= 6 D; fc_layernorm too). */
 FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64_t d_stride, const int32_t* gather,
                      const float* gamma, const float* beta, void* y, int64_t y_stride, int32_t kind, int32_t rows,
                      int32_t D, int32_t write_x, fc_stream stream);
 /* Multi-head attention over packed rows: qkv [n_seq * S, 3 * heads * 64] (q | k | v, head dim 64) -> out
  * [n_seq * S, heads * 64], softmax(q k^T / 8 [+ causal mask]) v per (sequence, head), as nn.MultiheadAttention inside
- * slip.py:366-380.  Any S in fp32; bf16: causal up to 224 tokens, non-causal any S (K/V streamed beyond 224). */
+ * slip.py:366-380.  Any S in fp32; bf16: causal up to 224 tokens, non-causal any S (K/V streamed beyond 224).
+ * precision 2: fp32 qkv in, six-plane bf16 rows out (fc_split6 layout; non-causal, 113..224 tokens). */
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
