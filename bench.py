@@ -33,6 +33,9 @@ The same JSON line carries
     device path over the whole batch, and on the CPU sample the device path ("gpu"), the oracle ("ref") and "delta".
   * "cpu_baseline": the CPU oracle (oracle/clip_oracle.py, kind "port") timed on this host's cores over a bounded
     sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample.
+  * `fp32_split_mode`: the same step with `precision="fp32x6"` - the visual tower's block GEMMs on the bf16 matrix
+    cores over split-fp32 operands (fc_config.split_gemm) - with its parity against the fp32 path and the oracle.
+    A labelled secondary mode like `bf16_mode`; never `value`.
   * `kd_training_step` (N = 1 only, after the timed region): the distillation training step at one
     rank's share of BASELINE configs[4]; never part of `value`.
 """
@@ -355,6 +358,86 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
     return out, (ev, et, all_ranks)
 
 
+def run_split_mode(sd, video, text, args, world, rank, device, backend):
+    """Secondary leg `fp32_split_mode` (precision "fp32x6"): the same step with the visual tower's block GEMMs on the bf16
+    matrix cores over split-fp32 operands (three bf16 numbers per value, six bf16 products per fp32 product, fp32
+    accumulate) - fp32 accuracy from the pipe that is 16x faster than the fp32-input one.  Timed like the headline; the
+    per-kernel figures come from one instrumented extra step."""
+    import torch.distributed as dist
+    from fitclip_amd import distributed as D
+    from fitclip_amd import ops
+    from fitclip_amd.clip_model import build_clip
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+
+    enc = ClipVideoTextEncoder(build_clip(sd, precision="fp32x6", device=device), num_frames=args.frames)
+    n_local = args.clips
+    counts = [n_local] * world
+
+    def step():
+        ev, et = enc(video=video, text=text)
+        scores = ops.similarity(et, D.all_gather_rows(ev, counts))
+        return ev, et, D.all_gather_rows(ops.ranks(scores, rank * n_local), counts)
+
+    def fence():
+        torch.cuda.synchronize()
+        if D.collectives_active():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev, et, all_ranks = step()
+    fence()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if D.collectives_active():
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    enc.model.profile(16384)
+    enc.model.profile_reset()
+    overlap, enc.overlap_text = enc.overlap_text, False
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    split_elapsed = time.perf_counter() - t1
+    enc.overlap_text = overlap
+    records = enc.model.profile_records()
+    enc.model.profile(0)
+    six = [r for r in records if r["kind"] == 0 and r["epilogue"] in (6, 7) and r["ms"] > 0]
+    by = defaultdict(lambda: [0.0, 0])
+    for r in six:
+        by[(r["epilogue"], r["N"], r["K"], r["M"])][0] += r["ms"]
+        by[(r["epilogue"], r["N"], r["K"], r["M"])][1] += 1
+    (epi, N, K6, M), (ms, cnt) = max(by.items(), key=lambda kv: kv[1][0])
+    bf16_flops = 2.0 * M * N * K6  # executed on the bf16 pipe: six products per fp32 product
+    six_ms = sum(r["ms"] for r in six)
+    six_flops = sum(2.0 * r["M"] * r["N"] * r["K"] for r in six)
+    step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
+    other = aggregate(records)[1]
+    return {
+        "value": round(n_local * world * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate; LayerNorm, "
+                 "softmax, residual stream, patch embedding and the text tower in plain fp32",
+        "roofline": {"bound": "mfma", "kernel": f"gemm_pipelined_kernel<256x256><bf16 six-plane operands,"
+                                                f"{ {6: 'bias_f32_out', 7: 'bias_quickgelu_six_plane_out'}[epi] }> M={M} N={N} K={K6} (= 6 x {K6 // 6})",
+                     "achieved": round(bf16_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                     "frac": round(bf16_flops * cnt / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),
+                     "fp32_equivalent_tflops": round(bf16_flops / 6 * cnt / (ms * 1e-3) / 1e12, 1),
+                     "launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "traffic": None,
+                     "timing": "hipEvent pairs in the instrumented extra step"},
+        "six_plane_gemms": {"achieved": round(six_flops / (six_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s of bf16 MFMA",
+                            "frac": round(six_flops / (six_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),
+                            "fp32_equivalent_tflops": round(six_flops / 6 / (six_ms * 1e-3) / 1e12, 1),
+                            "share_of_step_time": round(six_ms / (split_elapsed * 1e3), 4)},
+        "whole_path_fp32_equivalent_tflops": round(step_flops * args.steps / elapsed / 1e12, 2),
+        "time_split": {**{k: {"share_of_step_time": round(v[0] / (split_elapsed * 1e3), 4), "launches": v[1],
+                              "avg_launch_ms": round(v[0] / max(1, v[1]), 4)} for k, v in other.items()},
+                       "instrumented_step_ms": round(split_elapsed * 1e3, 3)},
+    }, (ev, et, all_ranks)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,6 +446,7 @@ def main() -> None:
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"],
                     help="headline precision; fp32 = the reference's (default).  bf16 here is for kernel work only")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-operand run")
+    ap.add_argument("--no-split-mode", action="store_true", help="skip the secondary split-fp32 run (fp32_split_mode)")
     ap.add_argument("--clips", type=int, default=256, help="clips (= captions) per GPU per step")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--chunk-frames", type=int, default=0)
@@ -474,6 +558,19 @@ def main() -> None:
                        "statistics); narrower than the reference's fp32, so it is never `value`")
         result["bf16_mode"] = b16
 
+    ev6 = et6 = None
+    if not args.no_split_mode and args.precision == "fp32":
+        s6, (ev6, et6, ranks6) = run_split_mode(sd, video, text, args, world, rank, device, args.backend)
+        m6 = D.metrics_from_ranks(ranks6.cpu().numpy())
+        s6["retrieval"] = m6
+        s6["recall_delta_vs_fp32_path"] = {k: round(m6[k] - metrics[k], 6) for k in ("r1", "r5", "r10", "mr")}
+        s6["ranks_identical_to_fp32_path"] = bool(torch.equal(ranks6, all_ranks))
+        s6["embedding_max_abs_vs_fp32_path"] = {"video": float((ev6 - ev).abs().max()), "text": float((et6 - et).abs().max())}
+        s6["speedup_vs_headline"] = round(s6["value"] / result["value"], 3)
+        s6["note"] = ("secondary mode, never `value`: products are formed on the bf16 pipe, but from exact three-term splits "
+                      "of the fp32 operands - see parity on the CPU sample (`on_sample`) at the fp32 tolerances")
+        result["fp32_split_mode"] = s6
+
     if rank == 0 and world == 1 and not args.no_train_leg and n_local >= 4:
         result["kd_training_step"] = training_leg({**sd, **unplanted}, video, ids, args, dims, device)
 
@@ -524,6 +621,15 @@ def main() -> None:
             "ref_min_top2_margin": float((top2[:, 0] - top2[:, 1]).min()),
             "ref_offdiag_cosine_std": float(torch.nn.functional.normalize(ev_ref, dim=1).mm(
                 torch.nn.functional.normalize(ev_ref, dim=1).T)[~torch.eye(k, dtype=torch.bool)].std())})
+        if ev6 is not None:
+            m6s, s6s, r6 = sample_metrics(et6, ev6)
+            result["fp32_split_mode"]["on_sample"] = {
+                "gpu": m6s, "ref": ref_m, "delta": {kk: round(m6s[kk] - ref_m[kk], 6) for kk in ("r1", "r5", "r10", "mr")},
+                "video_max_abs": (ev6[:k].cpu() - ev_ref).abs().max().item(),
+                "text_max_abs": (et6[:k].cpu() - et_ref).abs().max().item(),
+                "score_max_abs": float((s6s - s_ref).abs().max()),
+                "ranks_identical": bool(torch.equal(r6.long(), ref_ranks.long())),
+                "tolerance": "embeddings <= 2e-5, scores <= 5e-5, identical ranks (SURVEY 8(c), the fp32 bar)"}
         if ev16 is not None:
             m16s, s16, r16 = sample_metrics(et16, ev16)
             result["bf16_mode"]["on_sample"] = {

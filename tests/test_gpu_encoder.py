@@ -604,7 +604,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     """`python bench.py --gpus 2 --backend gloo`: the bench launches its own ranks, shards the clips, gathers embeddings
     and ranks, and prints one line whose whole-job value counts both ranks' clips."""
     line = _run(["bench.py", "--gpus", "2", "--backend", "gloo", "--clips", "16", "--frames", "2", "--steps", "1",
-                 "--warmup", "1", "--no-bf16-mode", "--no-cpu-baseline", "--cpu-sample-clips", "8"])
+                 "--warmup", "1", "--no-bf16-mode", "--no-split-mode", "--no-cpu-baseline", "--cpu-sample-clips", "8"])
     assert line["n_gpus"] == 2 and line["dtype"] == "fp32" and line["scaling"] == "weak"
     assert line["retrieval"]["n"] == 32 and line["value"] > 0
     assert line["retrieval"]["r1"] > 0.2  # rank 0's captions are planted on their clips; chance would be 1/32

@@ -47,7 +47,7 @@ def test_bench_runs_its_rccl_path_on_one_rank():
     """`bench.py` under a one-rank torch.distributed.run with forced collectives: process group on the device,
     broadcast of the planted tensors, all-gathers inside the timed steps, barrier + MAX all-reduce around them."""
     out = _launch([str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--clips", "16", "--frames", "2",
-                   "--no-cpu-baseline", "--no-bf16-mode", "--no-train-leg"])
+                   "--no-cpu-baseline", "--no-bf16-mode", "--no-split-mode", "--no-train-leg"])
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["collectives"].startswith("nccl process group"), out["config"]
     assert 0.0 <= out["retrieval"]["r1"] <= 1.0 and out["retrieval"]["n"] == 16

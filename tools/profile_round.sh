@@ -33,7 +33,7 @@ else
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi0E|365|1e9|$rows|768|3072|bias"
 fi
-common="--precision $prec --no-bf16-mode --no-cpu-baseline --no-train-leg"
+common="--precision $prec --no-bf16-mode --no-split-mode --no-cpu-baseline --no-train-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup 2 $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
 echo "trace pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_fetch_$prec.err"
