@@ -39,10 +39,35 @@ __device__ __forceinline__ void store_x6_activation(bf16* row_out, int col, cons
   *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p1;
   *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p3;
 }
-// 4 columns starting at column c of an output row
+// The same image written by a FULL wave whose lanes 2k, 2k + 1 hold the adjacent column blocks c (c % 8 == 0) and c + 4
+// (the LayerNorm kernels): the two lanes exchange their planes (DPP quad_perm, no LDS) and each writes three 16-byte
+// chunks - the even lane plane slots 0, 2, 4, the odd lane slots 1, 3, 5 - so one store instruction covers 128
+// contiguous bytes per 32-column group instead of 64 in 8-byte pieces.
+__device__ __forceinline__ unsigned lane_xor1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+}
+__device__ __forceinline__ void store_x6_paired(bf16* row_out, int col, const f32x4& x, int lane) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  bf16x4 p1, p2, p3;
+  split3(x, p1, p2, p3);
+  const u32x2 a1 = __builtin_bit_cast(u32x2, p1), a2 = __builtin_bit_cast(u32x2, p2), a3 = __builtin_bit_cast(u32x2, p3);
+  const u32x2 b1 = {lane_xor1(a1[0]), lane_xor1(a1[1])}, b2 = {lane_xor1(a2[0]), lane_xor1(a2[1])},
+              b3 = {lane_xor1(a3[0]), lane_xor1(a3[1])};
+  const bool odd = lane & 1;
+  auto chunk = [&](const u32x2& own, const u32x2& other) {  // 8 columns in column order
+    return odd ? u32x4{other[0], other[1], own[0], own[1]} : u32x4{own[0], own[1], other[0], other[1]};
+  };
+  const int c8 = col & ~7;
+  bf16* g = row_out + (c8 / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (c8 % X6_CHUNK) + (odd ? X6_CHUNK : 0);
+  *reinterpret_cast<u32x4*>(g) = chunk(a1, b1);                                        // slots 0 / 1: p1
+  *reinterpret_cast<u32x4*>(g + 2 * X6_CHUNK) = chunk(a2, b2);                         // slots 2 / 3: p2
+  *reinterpret_cast<u32x4*>(g + 4 * X6_CHUNK) = odd ? chunk(a3, b3) : chunk(a1, b1);   // slot 4: p1, slot 5: p3
+}
+// 4 columns starting at column c of an output row (called by every lane of the wave, lane l on columns .. + 4 l)
 template <typename OutT> __device__ __forceinline__ void put4_at(OutT* row, int c, const f32x4& v) { put4<OutT>(row + c, v); }
 template <> __device__ __forceinline__ void put4_at<x6_t>(x6_t* row, int c, const f32x4& v) {
-  store_x6_activation(reinterpret_cast<bf16*>(row), c, v);
+  store_x6_paired(reinterpret_cast<bf16*>(row), c, v, (int)(threadIdx.x & 63));
 }
 template <typename OutT> constexpr int kOutCols = 1;       // output elements per input column
 template <> constexpr int kOutCols<x6_t> = X6_PLANES;

@@ -256,7 +256,7 @@ def test_evaluate_driver_reproduces_config1_golden(golden_dir, capsys):
     assert abs(out["loss/val"] - float(g["loss_val"])) < 2e-3
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x6", "bf16"])
 @pytest.mark.parametrize("clips,frames,n_text", [(256, 8, 256), (1024, 16, 1024)])
 def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_text, precision):
     """BASELINE configs[1] (256 clips x 8 frames + 256 texts) and one rank's shard of configs[3] (1024 clips x 16
