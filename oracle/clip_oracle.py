@@ -41,7 +41,7 @@ TensorDict = Mapping[str, torch.Tensor]
 # ----------------------------------------------------------------------------------------------- transformer blocks
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """slip.py:350-356 (LayerNorm computed in float32, eps = nn.LayerNorm default 1e-5)."""
-    return F.layer_norm(x.float(), (x.shape[-1],), w, b, 1e-5)
+    return F.layer_norm(x.to(w.dtype), (x.shape[-1],), w, b, 1e-5)  # float32 weights: the reference's fp32 LayerNorm; float64 weights: the truth run of the tests
 
 
 def quick_gelu(x: torch.Tensor) -> torch.Tensor:
@@ -100,7 +100,7 @@ def encode_image(sd: TensorDict, images: torch.Tensor) -> torch.Tensor:
     w = sd["visual.conv1.weight"]
     width, patch = w.shape[0], w.shape[-1]
     heads = width // 64
-    x = F.conv2d(images.float(), w, None, stride=patch)  # [N, width, g, g]
+    x = F.conv2d(images.to(w.dtype), w, None, stride=patch)  # [N, width, g, g]
     x = x.reshape(x.shape[0], width, -1).permute(0, 2, 1)  # [N, g*g, width]
     cls = sd["visual.class_embedding"].expand(x.shape[0], 1, width)
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]

@@ -173,3 +173,24 @@ def test_split_mode_needs_fp32_and_cannot_train(tiny_state_dict):
     model = build_clip(tiny_state_dict, precision="fp32x6", device=DEV)
     with pytest.raises(ValueError):
         StudentTrainer(ClipVideoTextEncoder(model))
+
+
+def test_split_mode_is_as_close_to_float64_as_fp32_arithmetic_itself(vitb16_state_dict):
+    """Distance to the TRUTH (the oracle evaluated in float64) of three fp32-grade evaluations of ViT-B/16 embeddings:
+    the oracle in float32 (the reference's arithmetic on a CPU), the fp32-MFMA path and the split-fp32 path.  The split
+    path must not be further from the truth than ordinary fp32 arithmetic is."""
+    from oracle import clip_oracle as O
+    d = synth.VIT_B_16
+    sd32 = O.to_torch(vitb16_state_dict)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    video = torch.from_numpy(synth.make_video(6, 2, d, seed=77))
+    with torch.inference_mode():
+        truth = O.encode_video(sd64, video.double())
+        cpu32 = O.encode_video(sd32, video)
+    err = {"oracle fp32": float((cpu32.double() - truth).abs().max())}
+    for precision in ("fp32", "fp32x6"):
+        enc = ClipVideoTextEncoder(build_clip(vitb16_state_dict, precision=precision, device=DEV))
+        err[precision] = float((enc.encode_video(video.to(DEV)).cpu().double() - truth).abs().max())
+    print("max |embedding - float64 truth|:", err)
+    assert err["fp32x6"] < 1e-6 and err["fp32"] < 1e-6
+    assert err["fp32x6"] <= 2.0 * max(err["oracle fp32"], err["fp32"]) + 5e-8, err
