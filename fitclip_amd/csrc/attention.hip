@@ -805,27 +805,48 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
       }
     }
   }
+  if constexpr (X6) {
+    // Six-plane rows: the 64 columns of a head are two 32-column groups = 2 x 384 contiguous bytes per query row.  Each
+    // wave stages the three planes of a 16-row x 32-column patch in its own 3 KiB of the (now idle) K/V buffers
+    // (16-byte chunk ^ (row >> 2) & 3) and writes them out as whole rows: 64 lanes x 16 bytes = 2.67 rows per store.
+    __syncthreads();  // every wave is done reading K / V
+    char* stg = smem + wave * 4096;
+    const int sub = lane & 3;
 #pragma unroll
-  for (int qi = 0; qi < QPW; ++qi) {
-    const int query = qtile[qi] * 16 + r;
-    const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
-    if (query < S) {
-      if constexpr (X6) {
-        bf16* orow = reinterpret_cast<bf16*>(out) + ((long)seq * S + query) * (X6_PLANES * D);
+    for (int qi = 0; qi < QPW; ++qi) {
+      const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
+      const int q0 = qtile[qi] * 16;
+      if (q0 >= S) continue;  // wave-uniform
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const int col = h * 64 + 16 * n + 4 * g;
+      for (int gs = 0; gs < 2; ++gs) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
           bf16x4 p1, p2, p3;
-          split3(o[qi][n] * inv, p1, p2, p3);
-          bf16* gp = orow + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
-          *reinterpret_cast<bf16x4*>(gp) = p1;
-          *reinterpret_cast<bf16x4*>(gp + X6_CHUNK) = p1;
-          *reinterpret_cast<bf16x4*>(gp + 2 * X6_CHUNK) = p2;
-          *reinterpret_cast<bf16x4*>(gp + 3 * X6_CHUNK) = p2;
-          *reinterpret_cast<bf16x4*>(gp + 4 * X6_CHUNK) = p1;
-          *reinterpret_cast<bf16x4*>(gp + 5 * X6_CHUNK) = p3;
+          split3(o[qi][2 * gs + nh] * inv, p1, p2, p3);
+          const int off = r * 64 + (((nh * 2 + (g >> 1)) ^ ((r >> 2) & 3)) << 4) + ((g & 1) << 3);
+          *reinterpret_cast<bf16x4*>(stg + off) = p1;
+          *reinterpret_cast<bf16x4*>(stg + 1024 + off) = p2;
+          *reinterpret_cast<bf16x4*>(stg + 2048 + off) = p3;
         }
-      } else {
+        bf16* obase = reinterpret_cast<bf16*>(out) + ((long)seq * S + q0) * (X6_PLANES * D) +
+                      (h * 2 + gs) * (X6_CHUNK * X6_PLANES);
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          const int idx = it * 64 + lane, row = idx / 24, ch = idx - row * 24;  // 24 chunks of 16 bytes per row
+          const int slot = ch >> 2;                                             // planes [p1 p1 p2 p2 p1 p3]
+          const int plane = slot == 5 ? 2 : (slot == 2 || slot == 3) ? 1 : 0;
+          const bf16x8 val = *reinterpret_cast<const bf16x8*>(stg + plane * 1024 + row * 64 + (((ch & 3) ^ ((row >> 2) & 3)) << 4));
+          if (q0 + row < S) *reinterpret_cast<bf16x8*>(obase + (long)row * (X6_PLANES * D) + ch * 8) = val;
+        }
+      }
+    }
+    (void)sub;
+  } else {
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+      const int query = qtile[qi] * 16 + r;
+      const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
+      if (query < S) {
         float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
 #pragma unroll
         for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[qi][n] * inv;

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--lr", type=float, default=3e-6, help="AdamW learning rate (config/trainer.yaml:21-23)")
-    ap.add_argument("--teacher-precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--teacher-precision", default="fp32", choices=["fp32", "fp32x6", "bf16"])
     ap.add_argument("--teacher-on-labeled", action="store_true",
                     help="run the teacher over the labeled half as well (the reference's literal schedule; its output is never read)")
     a = ap.parse_args()
@@ -69,13 +69,13 @@ def main():
     el = time.perf_counter() - t0
     fwd = a.clips * (a.frames * GF_PER_FRAME + GF_PER_TEXT)
     teacher_share = 1.0 if a.teacher_on_labeled else (a.clips - a.clips // 2) / a.clips  # the half whose loss reads the teacher
-    flops = (3 + (teacher_share if a.teacher_precision == "fp32" else 0.0)) * fwd
+    flops = (3 + (teacher_share if a.teacher_precision != "bf16" else 0.0)) * fwd
     res = {"metric": "KD training step, one rank's share of BASELINE configs[4]", "clips": a.clips, "frames": a.frames,
            "teacher_precision": a.teacher_precision, "teacher_rows": "all" if a.teacher_on_labeled else "unlabeled half only",
            "ms_per_step": round(el / a.steps * 1e3, 2), "pairs_per_s": round(a.clips * a.steps / el, 2),
            "tflops_fp32_mfma": round(flops * a.steps / el / 1e12, 2),
            "frac_of_157.3": round(flops * a.steps / el / 1e12 / 157.3, 4),
-           "note": ("FLOPs = 3 x student forward (forward + dgrad + wgrad) + the fp32 teacher forward over the rows it runs on" if a.teacher_precision == "fp32" else
+           "note": ("FLOPs = 3 x student forward (forward + dgrad + wgrad) + the fp32 teacher forward over the rows it runs on" if a.teacher_precision != "bf16" else
                     "FLOPs = 3 x student forward; the bf16 teacher forward is inside the step time but not in the FLOP count"),
            "phases_ms": {k: round(v / a.steps * 1e3, 2) for k, v in phases.items()}, "lr": a.lr, "losses (the same batch every step)": [round(x, 6) for x in losses],
            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
