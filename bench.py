@@ -438,6 +438,21 @@ def run_split_mode(sd, video, text, args, world, rank, device, backend):
     }, (ev, et, all_ranks)
 
 
+def guarded(result, key, world, fn):
+    """Secondary legs must not cost the headline line: on ONE rank a failing leg is reported under its key and the run goes
+    on (with more ranks an exception propagates - a rank that skipped the leg's collectives would hang the others)."""
+    if world > 1:
+        return fn()
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        result[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -546,35 +561,51 @@ def main() -> None:
     }
 
     ev16 = et16 = None
-    if not args.no_bf16_mode and args.precision == "fp32":
+
+    def bf16_leg():
         torch.cuda.empty_cache()
-        b16, (ev16, et16, ranks16) = run_mode("bf16", sd, video, text, args, world, rank, device, args.backend, False)
+        b16, (v16, t16, ranks16) = run_mode("bf16", sd, video, text, args, world, rank, device, args.backend, False)
         m16 = D.metrics_from_ranks(ranks16.cpu().numpy())
         b16["retrieval"] = m16
         b16["recall_delta_vs_fp32_path"] = {k: round(m16[k] - metrics[k], 6) for k in ("r1", "r5", "r10", "mr")}
-        b16["embedding_max_abs_vs_fp32_path"] = {"video": float((ev16 - ev).abs().max()),
-                                                 "text": float((et16 - et).abs().max())}
+        b16["embedding_max_abs_vs_fp32_path"] = {"video": float((v16 - ev).abs().max()), "text": float((t16 - et).abs().max())}
         b16["note"] = ("secondary mode: bf16 MFMA operands (fp32 accumulate, fp32 residual stream / LayerNorm / softmax "
                        "statistics); narrower than the reference's fp32, so it is never `value`")
         result["bf16_mode"] = b16
+        return v16, t16
+
+    if not args.no_bf16_mode and args.precision == "fp32":
+        got = guarded(result, "bf16_mode", world, bf16_leg)
+        if got is not None:
+            ev16, et16 = got
 
     ev6 = et6 = None
-    if not args.no_split_mode and args.precision == "fp32":
-        s6, (ev6, et6, ranks6) = run_split_mode(sd, video, text, args, world, rank, device, args.backend)
+
+    def split_leg():
+        torch.cuda.empty_cache()
+        s6, (v6, t6, ranks6) = run_split_mode(sd, video, text, args, world, rank, device, args.backend)
         m6 = D.metrics_from_ranks(ranks6.cpu().numpy())
         s6["retrieval"] = m6
         s6["recall_delta_vs_fp32_path"] = {k: round(m6[k] - metrics[k], 6) for k in ("r1", "r5", "r10", "mr")}
         s6["ranks_identical_to_fp32_path"] = bool(torch.equal(ranks6, all_ranks))
-        s6["embedding_max_abs_vs_fp32_path"] = {"video": float((ev6 - ev).abs().max()), "text": float((et6 - et).abs().max())}
+        s6["embedding_max_abs_vs_fp32_path"] = {"video": float((v6 - ev).abs().max()), "text": float((t6 - et).abs().max())}
         s6["speedup_vs_headline"] = round(s6["value"] / result["value"], 3)
         s6["note"] = ("secondary mode, never `value`: products are formed on the bf16 pipe, but from exact three-term splits "
                       "of the fp32 operands - see parity on the CPU sample (`on_sample`) at the fp32 tolerances")
         result["fp32_split_mode"] = s6
+        return v6, t6
+
+    if not args.no_split_mode and args.precision == "fp32":
+        got = guarded(result, "fp32_split_mode", world, split_leg)
+        if got is not None:
+            ev6, et6 = got
 
     if rank == 0 and world == 1 and not args.no_train_leg and n_local >= 4:
-        result["kd_training_step"] = training_leg({**sd, **unplanted}, video, ids, args, dims, device)
+        got = guarded(result, "kd_training_step", world, lambda: training_leg({**sd, **unplanted}, video, ids, args, dims, device))
+        if got is not None:
+            result["kd_training_step"] = got
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    def cpu_leg():
         from oracle import clip_oracle as O
         cores = min(host_cores(), 64)
         torch.set_num_threads(cores)
@@ -637,6 +668,10 @@ def main() -> None:
                 "video_max_abs": (ev16[:k].cpu() - ev_ref).abs().max().item(),
                 "text_max_abs": (et16[:k].cpu() - et_ref).abs().max().item(),
                 "ranks_identical": bool(torch.equal(r16.long(), ref_ranks.long()))}
+        return True
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        guarded(result, "cpu_baseline", world, cpu_leg)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if grouped:
