@@ -296,18 +296,11 @@ int gemm_x6(fc_handle* h, int epi, const void* A6, const void* W6, const float* 
   return launch_gemm(PREC_BF16, epi, a, 0, st);
 }
 
-// can every block GEMM of a pass of M rows run on the pipelined kernel (enough tiles, 32-bit operand offsets)?
+// The six-plane GEMMs only exist on the pipelined kernel: a pass qualifies when its widest operand - the six-plane MLP
+// hidden rows, 48 w bytes each - stays below the 4 GiB of the kernel's 32-bit operand offsets, and K = 6 w spans the
+// three K-tiles its prologue assumes.
 bool x6_pass_ok(int M, int w) {
-  const int shapes[4][2] = {{3 * w, w}, {w, w}, {4 * w, w}, {w, 4 * w}};
-  for (auto& sh : shapes) {
-    GemmArgs a{};
-    a.M = M; a.N = sh[0]; a.K = X6_PLANES * sh[1]; a.lda = a.K; a.ldw = a.K;
-    a.ldc = sh[0] == 4 * w ? X6_PLANES * sh[0] : sh[0];
-    static const float kBias = 0.f;
-    a.bias = reinterpret_cast<const float*>((uintptr_t)&kBias & ~(uintptr_t)15);  // only its alignment is inspected
-    if (gemm_resolved_tile(PREC_BF16, EPI_BIAS_F32, a, 0) != 3) return false;
-  }
-  return true;
+  return M > 0 && (size_t)M * 4 * w * X6_PLANES * 2 < (1ull << 32) && X6_PLANES * w >= 3 * 64;  // K-tile of the bf16 kernel: 64 columns
 }
 
 int run_blocks_x6(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,

@@ -1,3 +1,4 @@
+"""add+LayerNorm at 100864 rows x 768: fp32 output (16 B per element) vs six-plane output (24 B per element)."""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from fitclip_amd import ops

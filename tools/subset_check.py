@@ -1,3 +1,4 @@
+"""Embeddings do not depend on the batch they are computed in: a sub-batch against the same rows of the full batch (bit-equal)."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from fitclip_amd import synth
