@@ -201,11 +201,10 @@ def load_traffic(precision, shape, epilogue):
         if doc.get("source_fingerprint", t.get("source_fingerprint")) != fp:
             return None, (f"{name} is stale: PMC pass made with kernel sources "
                           f"{doc.get('source_fingerprint', t.get('source_fingerprint'))}, tree is {fp}")
-        esz = 2 if precision == "bf16" else 4
         M, N, K = shape
         note = (f"PMC pass ({name}, sources {fp}): fetch {t['fetch_bytes_per_launch'] / 1e6:.0f} MB + write "
                 f"{t['write_bytes_per_launch'] / 1e6:.0f} MB per launch; algorithmic "
-                f"{(M * K + N * K + M * N) * esz / 1e6:.0f} MB")
+                f"{t.get('algorithmic_bytes_per_launch', (M * K + N * K + M * N) * (2 if precision == 'bf16' else 4)) / 1e6:.0f} MB")
         return t["hbm_bytes_per_launch"], note
     return None, "no PMC pass committed for this precision"
 
@@ -412,6 +411,8 @@ def run_split_mode(sd, video, text, args, world, rank, device, backend):
         by[(r["epilogue"], r["N"], r["K"], r["M"])][1] += 1
     (epi, N, K6, M), (ms, cnt) = max(by.items(), key=lambda kv: kv[1][0])
     bf16_flops = 2.0 * M * N * K6  # executed on the bf16 pipe: six products per fp32 product
+    epi_name = {6: "bias_f32_out", 7: "bias_quickgelu_six_plane_out"}[epi]
+    traffic, traffic_note = load_traffic("fp32x6", (M, N, K6), epi_name)
     six_ms = sum(r["ms"] for r in six)
     six_flops = sum(2.0 * r["M"] * r["N"] * r["K"] for r in six)
     step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
@@ -421,11 +422,11 @@ def run_split_mode(sd, video, text, args, world, rank, device, backend):
         "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate; LayerNorm, "
                  "softmax, residual stream, patch embedding and the text tower in plain fp32",
         "roofline": {"bound": "mfma", "kernel": f"gemm_pipelined_kernel<256x256><bf16 six-plane operands,"
-                                                f"{ {6: 'bias_f32_out', 7: 'bias_quickgelu_six_plane_out'}[epi] }> M={M} N={N} K={K6} (= 6 x {K6 // 6})",
+                                                f"{epi_name}> M={M} N={N} K={K6} (= 6 x {K6 // 6})",
                      "achieved": round(bf16_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                      "frac": round(bf16_flops * cnt / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),
                      "fp32_equivalent_tflops": round(bf16_flops / 6 * cnt / (ms * 1e-3) / 1e12, 1),
-                     "launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "traffic": None,
+                     "launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "traffic": traffic, "traffic_note": traffic_note,
                      "timing": "hipEvent pairs in the instrumented extra step"},
         "six_plane_gemms": {"achieved": round(six_flops / (six_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s of bf16 MFMA",
                             "frac": round(six_flops / (six_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),

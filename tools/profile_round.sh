@@ -2,6 +2,7 @@
 # Reproduces the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun, from the repo root):
 #   tools/profile_round.sh r02 fp32        # the headline precision
 #   tools/profile_round.sh r02 bf16        # the secondary mode
+#   tools/profile_round.sh r02 fp32x6      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on)
 # 1. kernel trace + stats of the bench command for that precision (CPU leg and the other precision off);
 # 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) and 4. an SQ pass for the dominant kernel (c_fc + QuickGELU GEMM).
 # Raw output goes to gpurun_out/prof_*; summaries to profiles/ AND gpurun_out/profiles_<tag>/ (the latter travels back).
@@ -28,12 +29,23 @@ if [ "$prec" = fp32 ]; then
   steps=3; chunk=1663; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 0,|9800|1e9|$rows|768|3072|bias"
-else
+elif [ "$prec" = bf16 ]; then
   steps=5; chunk=512; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi0E|365|1e9|$rows|768|3072|bias"
+else
+  # fp32x6 = the split-fp32 leg of the fp32 bench run (passes of 512 frames; six-plane operands: K' = 6 K): c_fc with the
+  # QuickGELU + six-plane epilogue has its own instantiation (epilogue 7); c_proj shares epilogue 6 with QKV / out_proj
+  # and is the only one of them above 2 ms (QKV 1.75, out_proj 0.6)
+  steps=3; chunk=512; rows=$((chunk * 197))
+  spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi7E|2000|1e9|$rows|3072|4608|bias_quickgelu_six_plane_out"
+  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi6E|2050|1e9|$rows|768|18432|bias_f32_out"
 fi
-common="--precision $prec --no-bf16-mode --no-split-mode --no-cpu-baseline --no-train-leg"
+if [ "$prec" = fp32x6 ]; then
+  common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
+else
+  common="--precision $prec --no-bf16-mode --no-split-mode --no-cpu-baseline --no-train-leg"
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup 2 $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
 echo "trace pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_fetch_$prec.err"
@@ -45,7 +57,9 @@ echo "sq pass done"
 cd "$repo"
 find "$out/prof_trace_$prec" -name "*kernel_stats.csv" -exec cp {} "$keep/${tag}_bench_${prec}_kernel_stats.csv" \;
 trace=$(find "$out/prof_trace_$prec" -name "*kernel_trace.csv" | head -1)
-python3 tools/trace_summary.py "$trace" $chunk $prec > "$keep/${tag}_bench_${prec}_trace_summary.txt"
+if [ "$prec" != fp32x6 ]; then  # (the split leg shares its trace with the fp32 leg: only the kernel table is kept)
+  python3 tools/trace_summary.py "$trace" $chunk $prec > "$keep/${tag}_bench_${prec}_trace_summary.txt"
+fi
 cp "$out/prof_trace_$prec.json" "$keep/${tag}_bench_${prec}_under_rocprof.json"
 f=$(find "$out/prof_fetch_$prec" -name "*counter_collection.csv" | head -1)
 w=$(find "$out/prof_write_$prec" -name "*counter_collection.csv" | head -1)
