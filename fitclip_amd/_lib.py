@@ -22,11 +22,19 @@ class FitclipHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3  # FC_ABI_VERSION of include/fitclip_hip.h
+
+
 class fc_config(C.Structure):
+    """`fc_config`; positional arguments start at `embed_dim` - `struct_size` (the first field, which fc_create checks
+    before it reads anything else) is filled in here."""
     _fields_ = [(n, C.c_int32) for n in (
-        "embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size", "context_length",
+        "struct_size", "embed_dim", "image_resolution", "vision_layers", "vision_width", "vision_patch_size", "context_length",
         "vocab_size", "transformer_width", "transformer_heads", "transformer_layers", "precision", "chunk_frames",
         "chunk_texts", "gemm_tile", "prune_last_block", "split_gemm")]
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
 
 
 class fc_prof_record(C.Structure):
@@ -85,6 +93,8 @@ SIGNATURES = {
     "fc_attention_backward": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "fc_layernorm_backward_scratch_bytes": (_sz, [_i32]),
     "fc_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "fc_token_embedding_backward_scratch_bytes": (_sz, [_i32, _i32]),
+    "fc_token_embedding_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "fc_dot": (_i32, [_vp, _vp, _sz, _f32, _f32, _vp, _vp]),
     "fc_transpose": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fc_adamw": (_i32, [_vp, _vp, _vp, _vp, _sz, _f64, _f64, _f64, _f64, _f64, _i32, _vp]),

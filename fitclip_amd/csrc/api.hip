@@ -407,10 +407,18 @@ using namespace fc;
 extern "C" {
 
 const char* fc_last_error(void) { return g_error.c_str(); }
-const char* fc_version(void) { return "fitclip_hip 0.1 (gfx950)"; }
+#define FC_STR2(x) #x
+#define FC_STR(x) FC_STR2(x)
+const char* fc_version(void) { return "fitclip_hip 0.3 (gfx950) abi " FC_STR(FC_ABI_VERSION); }
 
 int fc_create(const fc_config* cfg, fc_handle** out) {
   if (!cfg || !out) return fail(FC_EINVAL, "fc_create: null argument");
+  // the first four bytes say how large the CALLER believes the struct is: nothing else is read before they match
+  if (cfg->struct_size != (int32_t)sizeof(fc_config))
+    return fail(FC_EINVAL,
+                "fc_create: fc_config.struct_size is %d but this library's fc_config has %zu bytes (ABI %d): the binding "
+                "was written against another revision of include/fitclip_hip.h",
+                cfg->struct_size, sizeof(fc_config), FC_ABI_VERSION);
   const fc_config& c = *cfg;
   if (c.precision != FC_PREC_F32 && c.precision != FC_PREC_BF16) return fail(FC_EINVAL, "fc_create: precision");
   if (c.split_gemm && (c.precision != FC_PREC_F32 || c.vision_width % 256 || c.prune_last_block))

@@ -1,7 +1,7 @@
 // HBM-bound kernels of the training step (KD fine-tuning of the student, aligner/teacher_student.py:99-183): backward of
 // LayerNorm / pooling / L2-normalisation / the two similarity losses / the embeddings, QuickGELU forward on a saved
-// pre-activation, AdamW.  All reductions are two-stage with a fixed order (deterministic), except the token-embedding
-// scatter-add (float atomics, order-dependent in the last bits).
+// pre-activation, AdamW.  Every reduction has a fixed order (deterministic; no float atomics anywhere): two-stage
+// partial sums, and a row-ordered segmented sum for the token-embedding gradient.
 #include "common.h"
 
 #include <algorithm>
@@ -417,17 +417,104 @@ __global__ void __launch_bounds__(256) seq_sum_kernel(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(P + (size_t)t * D + c) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// dtok[ids[row]] += g[row]    (token_embedding gradient; float atomics).  One wave per row.
-__global__ void __launch_bounds__(256) token_scatter_add_kernel(const int64_t* __restrict__ ids,
-                                                                const float* __restrict__ g, float* __restrict__ dtok,
-                                                                int rows, int D, int vocab) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
-    long id = ids[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // same clamp as the forward gather
-    for (int c = lane; c < D; c += 64) unsafeAtomicAdd(dtok + id * D + c, g[(size_t)row * D + c]);
+// ---- token_embedding gradient: dtok[id] = sum of g[row] over the rows that hold `id`, IN ROW ORDER.  No float atomics:
+// SOT / EOT / pad rows collide in every caption, and an order-dependent sum there would make every later step of a run
+// differ in the last bits from its own replay (a resumed run, a second rank group).  Two kernels:
+//
+// (1) `token_order_kernel`, ONE workgroup: a stable counting sort of the row indices by id.  Rows are walked in chunks of
+//     1024; a row's position inside its id's segment = (rows of that id in earlier chunks, `cnt[id]` so far) + (earlier
+//     rows of the chunk with the same id, counted against the chunk's ids in LDS, four per ds_read_b128).  The first row
+//     of an id in the chunk then advances `cnt[id]` by the chunk's count - one writer per id, plain stores, ordered
+//     by the workgroup barrier.  After the walk `cnt` is the histogram; an exclusive scan over the vocabulary gives every
+//     segment's start, and `perm[start[id] + rank[row]] = row` lists each segment in ascending row order.
+// (2) `token_segment_sum_kernel`: one wave per (row, 64-column slice); only the FIRST row of an id works: it walks its
+//     id's segment of `perm` and adds the rows in that order (eight loads in flight, adds strictly sequential).
+__global__ void __launch_bounds__(1024) token_order_kernel(const int64_t* __restrict__ ids, int rows, int vocab,
+                                                           int* __restrict__ cnt, int* __restrict__ start,
+                                                           int* __restrict__ rank, int* __restrict__ perm) {
+  __shared__ __attribute__((aligned(16))) int sid[1024];
+  __shared__ int wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int v = tid; v < vocab; v += 1024) cnt[v] = 0;
+  for (int base = 0; base < rows; base += 1024) {
+    const int r = base + tid;
+    int id = -1;
+    if (r < rows) {
+      const long raw = ids[r];
+      id = (int)(raw < 0 ? 0 : (raw >= vocab ? vocab - 1 : raw));  // same clamp as the forward gather
+    }
+    sid[tid] = id;
+    __syncthreads();  // chunk ids visible; the previous chunk's cnt updates too
+    int before = 0, total = 0, prev = 0;
+    if (id >= 0) {
+      for (int j = 0; j < 1024; j += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(&sid[j]);
+        const int e0 = v.x == id, e1 = v.y == id, e2 = v.z == id, e3 = v.w == id;
+        total += e0 + e1 + e2 + e3;
+        before += (e0 & (j < tid)) + (e1 & (j + 1 < tid)) + (e2 & (j + 2 < tid)) + (e3 & (j + 3 < tid));
+      }
+      prev = cnt[id];
+      rank[r] = prev + before;
+    }
+    __syncthreads();  // every reader of cnt[id] and of sid is done
+    if (id >= 0 && before == 0) cnt[id] = prev + total;
   }
+  __syncthreads();
+  // exclusive scan of cnt over the vocabulary: a contiguous slice per thread, slices combined through wave + LDS scans
+  const int per = (vocab + 1023) / 1024;
+  const int v0 = min(tid * per, vocab), v1 = min(v0 + per, vocab);
+  int mine = 0;
+  for (int v = v0; v < v1; ++v) mine += cnt[v];
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int offset = incl - mine;
+  for (int w = 0; w < wave; ++w) offset += wtot[w];
+  for (int v = v0; v < v1; ++v) {
+    start[v] = offset;
+    offset += cnt[v];
+  }
+  __syncthreads();
+  for (int r = tid; r < rows; r += 1024) {
+    const long raw = ids[r];
+    const int id = (int)(raw < 0 ? 0 : (raw >= vocab ? vocab - 1 : raw));
+    perm[start[id] + rank[r]] = r;
+  }
+}
+
+__global__ void __launch_bounds__(256) token_segment_sum_kernel(const int64_t* __restrict__ ids,
+                                                                const float* __restrict__ g, float* __restrict__ dtok,
+                                                                int rows, int D, int vocab, const int* __restrict__ cnt,
+                                                                const int* __restrict__ start,
+                                                                const int* __restrict__ rank,
+                                                                const int* __restrict__ perm, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int slices = (D + 63) >> 6;
+  const long widx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = (int)(widx / slices), c = (int)(widx - (long)row * slices) * 64 + lane;
+  if (row >= rows || rank[row] != 0) return;  // wave-uniform: one wave per distinct id and column slice goes on
+  const long raw = ids[row];
+  const int id = (int)(raw < 0 ? 0 : (raw >= vocab ? vocab - 1 : raw));
+  const int* seg = perm + start[id];
+  const int n = cnt[id];
+  if (c >= D) return;
+  float acc = 0.f;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = g[(size_t)seg[k + u] * D + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; k < n; ++k) acc += g[(size_t)seg[k] * D + c];
+  float* out = dtok + (size_t)id * D + c;
+  *out = accumulate ? *out + acc : acc;
 }
 
 // x[i * S, :] = cls + pos0    (the CLS rows of the visual token stream; the fused inference entry never stores them)
@@ -554,12 +641,26 @@ int launch_seq_sum(const float* g, int n_seq, int S, int D, float* out_pos, floa
   return rc;
 }
 
-int launch_token_scatter_add(const int64_t* ids, const float* g, float* dtok, int rows, int D, int vocab,
-                             hipStream_t st) {
+size_t token_grad_scratch_bytes(int rows, int vocab) { return ((size_t)2 * vocab + (size_t)2 * rows) * sizeof(int); }
+
+// dtok[id, :] (+)= sum of g[row, :] over the rows with ids[row] == id, summed in row order; rows of dtok whose id does not
+// occur are left alone (the caller zeroes the table when it does not accumulate)
+int launch_token_grad(const int64_t* ids, const float* g, float* dtok, int rows, int D, int vocab, int accumulate,
+                      void* scratch, size_t scratch_bytes, hipStream_t st) {
   if (rows <= 0) return FC_OK;
-  hipLaunchKernelGGL(token_scatter_add_kernel, dim3(std::min((rows + 3) / 4, 2048)), dim3(256), 0, st, ids, g, dtok,
-                     rows, D, vocab);
-  FC_CHECK_LAUNCH("token scatter-add");
+  if (vocab <= 0 || D <= 0) return fail(FC_EINVAL, "token gradient: empty table");
+  if (!scratch || scratch_bytes < token_grad_scratch_bytes(rows, vocab) || ((uintptr_t)scratch & 15))
+    return fail(FC_ENOMEM, "token gradient: scratch needs %zu bytes", token_grad_scratch_bytes(rows, vocab));
+  int* cnt = static_cast<int*>(scratch);
+  int* start = cnt + vocab;
+  int* rank = start + vocab;
+  int* perm = rank + rows;
+  hipLaunchKernelGGL(token_order_kernel, dim3(1), dim3(1024), 0, st, ids, rows, vocab, cnt, start, rank, perm);
+  FC_CHECK_LAUNCH("token order");
+  const long waves = (long)rows * ((D + 63) / 64);
+  hipLaunchKernelGGL(token_segment_sum_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ids, g, dtok, rows, D,
+                     vocab, cnt, start, rank, perm, accumulate);
+  FC_CHECK_LAUNCH("token segment sum");
   return FC_OK;
 }
 

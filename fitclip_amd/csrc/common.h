@@ -172,8 +172,10 @@ int launch_kd_teacher_scale_grad(const float* scores, const float* teacher, int 
 // out_row0 = beta out_row0 + sums[0]
 int launch_seq_sum(const float* g, int n_seq, int S, int D, float* out_pos, float* out_row0, float beta, float* scratch,
                    size_t scratch_bytes, hipStream_t st);
-int launch_token_scatter_add(const int64_t* ids, const float* g, float* dtok, int rows, int D, int vocab,
-                             hipStream_t st);
+// token_embedding gradient as a fixed-order segmented sum (no float atomics): scratch holds 2 vocab + 2 rows ints
+size_t token_grad_scratch_bytes(int rows, int vocab);
+int launch_token_grad(const int64_t* ids, const float* g, float* dtok, int rows, int D, int vocab, int accumulate,
+                      void* scratch, size_t scratch_bytes, hipStream_t st);
 int launch_fill_cls(float* x, const float* cls, const float* pos0, int n_seq, int S, int D, hipStream_t st);
 
 // exp(x) for x <= 0 (softmax terms) in fp32: 2^(x log2 e) on v_exp_f32 (1 ulp) with the product's rounding error and the low

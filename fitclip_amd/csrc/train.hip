@@ -81,7 +81,8 @@ Arena carve_arena(const fc_handle* h, int tower, int n, char* base) {
 
 struct Scratch {
   float *g, *dA, *dB, *dh, *tn, *small;
-  size_t tn_bytes, small_bytes, total;
+  void* tok;
+  size_t tn_bytes, small_bytes, tok_bytes, total;
 };
 
 Scratch carve_scratch(const fc_handle* h, int tower, int n, char* base) {
@@ -108,6 +109,10 @@ Scratch carve_scratch(const fc_handle* h, int tower, int n, char* base) {
   s.tn = take(tn);
   s.small_bytes = std::max({colsum_scratch_bytes(Mi, 4 * d.w), layernorm_bwd_scratch_bytes(d.w), (size_t)d.S * w * 4});
   s.small = take(s.small_bytes);
+  if (tower == 1) {
+    s.tok_bytes = token_grad_scratch_bytes(Mi, h->cfg.vocab_size);
+    s.tok = take(s.tok_bytes);
+  }
   s.total = off;
   return s;
 }
@@ -383,7 +388,7 @@ int fc_encode_text_backward(fc_handle* h, const int64_t* ids, const float* dz, i
   if (!accumulate &&
       hipMemsetAsync(dtok, 0, (size_t)h->cfg.vocab_size * d.w * sizeof(float), st) != hipSuccess)
     return fail(FC_ELAUNCH, "fc_encode_text_backward: hipMemsetAsync failed");
-  return launch_token_scatter_add(ids, sc.g, dtok, (int)d.M(), d.w, h->cfg.vocab_size, st);
+  return launch_token_grad(ids, sc.g, dtok, (int)d.M(), d.w, h->cfg.vocab_size, accumulate ? 1 : 0, sc.tok, sc.tok_bytes, st);
 }
 
 int fc_pool_normalize_backward(const float* z, const float* dout, float* dz, int32_t n_clips, int32_t frames, int32_t dim,
@@ -426,6 +431,14 @@ int fc_layernorm_backward(const float* x, const float* dy, const float* gamma, f
                           fc_stream st) {
   return launch_layernorm_backward(x, D, nullptr, dy, PREC_F32, D, 0, gamma, dx, D, accumulate, rows, D, dgamma, dbeta, 0.f,
                                    static_cast<float*>(scratch), scratch_bytes, st);
+}
+size_t fc_token_embedding_backward_scratch_bytes(int32_t rows, int32_t vocab) {
+  return rows < 0 || vocab < 0 ? 0 : token_grad_scratch_bytes(rows, vocab);
+}
+int fc_token_embedding_backward(const int64_t* ids, const float* d_rows, float* d_table, int32_t rows, int32_t D,
+                                int32_t vocab, int32_t accumulate, void* scratch, size_t scratch_bytes, fc_stream st) {
+  if (!ids || !d_rows || !d_table) return fail(FC_EINVAL, "fc_token_embedding_backward: null argument");
+  return launch_token_grad(ids, d_rows, d_table, rows, D, vocab, accumulate ? 1 : 0, scratch, scratch_bytes, st);
 }
 int fc_dot(const float* a, const float* b, size_t n, float alpha, float beta, float* out, fc_stream st) {
   if (!a || !b || !out) return fail(FC_EINVAL, "fc_dot: null argument");

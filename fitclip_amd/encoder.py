@@ -58,6 +58,7 @@ class ClipVideoTextEncoder(VideoTextEncoder):
         self.mean, self.std = CLIP_MEAN, CLIP_STD
         self.overlap_text = _OVERLAP_TEXT  # two-stream forward (see `forward`); plain attribute, can be switched off
         self._side_stream = None  # second HIP stream of the two-stream forward (created on first use)
+        self._tokenizer = None    # ClipBpeTokenizer over `bpe_path`, built on first use (one native handle per encoder)
         # Same as the reference (:75-77): the CLIP temperature is unused, drop the parameter so it is not in
         # `named_parameters()` (WiSE) nor in the optimiser.
         if hasattr(self.model, "logit_scale"):
@@ -109,13 +110,23 @@ class ClipVideoTextEncoder(VideoTextEncoder):
 
     def get_tokenizer(self) -> TYPE_TOKENIZER:
         if self.bpe_path:
-            from .bpe import ClipBpeTokenizer
-            return ClipBpeTokenizer(self.bpe_path, self.model.context_length)
+            if self._tokenizer is None:
+                from .bpe import ClipBpeTokenizer
+                self._tokenizer = ClipBpeTokenizer(self.bpe_path, self.model.context_length)
+            return self._tokenizer
         return HashTokenizer(self.model.context_length, self.model.vocab_size)
 
     def decode_text(self, text: TYPE_TEXT_INPUT) -> Iterator[str]:
-        for ids in text["input_ids"]:
-            yield " ".join(f"<{int(t)}>" for t in ids if int(t) != 0)
+        """Reference :100-103: `clip._tokenizer.decode(ids)` per instance - EVERY id of the row goes through the BPE decoder,
+        so the string carries `<|startoftext|>`, `<|endoftext|>` and one decoded pad token per padded position, exactly as
+        the reference's prediction dumps do.  Accepts the batch mapping (`{"input_ids": [n, L]}`) or an iterable of
+        per-instance mappings (what the reference's loop indexes).  Without a vocabulary file (`bpe_path=None`: the
+        HashTokenizer is one-way) the ids are printed as `<id>` placeholders, padding dropped."""
+        rows = text["input_ids"] if isinstance(text, Mapping) else (instance["input_ids"] for instance in text)
+        tokenizer = self.get_tokenizer() if self.bpe_path else None
+        for ids in rows:
+            ids = [int(t) for t in ids]
+            yield tokenizer.decode(ids) if tokenizer is not None else " ".join(f"<{t}>" for t in ids if t != 0)
 
     def get_train_frame_sampler(self) -> FrameSampler:
         return RandomFromUniformIntervalsFrameSampler(self.num_frames)

@@ -210,6 +210,30 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out: Optional[
     return out
 
 
+def token_embedding_backward(ids: torch.Tensor, d_rows: torch.Tensor, vocab: int, out: Optional[torch.Tensor] = None,
+                             accumulate: bool = False) -> torch.Tensor:
+    """d_table[id] (+)= sum of d_rows[r] over the rows with ids[r] == id, added in row order (bit-reproducible: no float
+    atomics).  ids int64 [rows] (any shape, flattened), d_rows f32 [rows, D] -> f32 [vocab, D]."""
+    _dev(ids, "ids", torch.int64), _dev(d_rows, "d_rows", torch.float32)
+    rows, D = d_rows.shape
+    if ids.numel() != rows:
+        raise ValueError(f"{ids.numel()} ids for {rows} gradient rows")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an `out` to add to")
+        out = torch.zeros((vocab, D), dtype=torch.float32, device=d_rows.device)
+    _dev(out, "out", torch.float32)
+    if tuple(out.shape) != (vocab, D):
+        raise ValueError(f"out must be [{vocab}, {D}], got {tuple(out.shape)}")
+    lib = _lib.load()
+    scratch = torch.empty(lib.fc_token_embedding_backward_scratch_bytes(rows, vocab), dtype=torch.uint8, device=d_rows.device)
+    with torch.cuda.device(d_rows.device):
+        _lib.check(lib.fc_token_embedding_backward(ids.data_ptr(), d_rows.data_ptr(), out.data_ptr(), rows, D, vocab,
+                                                   int(accumulate), scratch.data_ptr(), scratch.numel(),
+                                                   _lib.current_stream()), "fc_token_embedding_backward")
+    return out
+
+
 def ranks(scores: torch.Tensor, target_offset: int = 0) -> torch.Tensor:
     """Position of column (i + target_offset) in the stable descending order of row i (aligner/metrics.py:16-20)."""
     if scores.device.type != "cuda" or scores.dtype != torch.float32 or scores.stride(1) != 1:

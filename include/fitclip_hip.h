@@ -46,9 +46,16 @@ typedef enum {
   FC_PREC_BF16 = 1 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream / LayerNorm / softmax          */
 } fc_precision;
 
+/* ABI revision of this header: bumped whenever a struct or a signature changes; the tail of fc_version() names it. */
+#define FC_ABI_VERSION 3
+
 /* Architecture: the keys of config/encoder/clip_from_scratch_vit_b_16.yaml:5-16 (heads = width / 64 as in
- * clip.model.CLIP).  Head dimension must be 64. */
+ * clip.model.CLIP).  Head dimension must be 64.
+ * `struct_size` is the FIRST field and must hold sizeof(fc_config) AS THE CALLER DECLARED IT: fc_create reads it before
+ * anything else and rejects a binding written against another revision of this struct (FC_EINVAL, with both sizes in
+ * fc_last_error()) instead of reading past the caller's memory.  Use FC_CONFIG_INIT in C. */
 typedef struct {
+  int32_t struct_size;        /* sizeof(fc_config) */
   int32_t embed_dim;          /* 512  */
   int32_t image_resolution;   /* 224  */
   int32_t vision_layers;      /* 12   */
@@ -73,6 +80,7 @@ typedef struct {
                                  the text tower and passes too small for the pipelined GEMM stay on the plain fp32
                                  path.  0 (default): fp32-input MFMA everywhere */
 } fc_config;
+#define FC_CONFIG_INIT {(int32_t)sizeof(fc_config)}
 
 typedef struct fc_handle fc_handle;
 
@@ -226,6 +234,15 @@ FC_API size_t fc_layernorm_backward_scratch_bytes(int32_t D);
 FC_API int fc_layernorm_backward(const float* x, const float* d_y, const float* gamma, float* d_x, int32_t accumulate,
                           int32_t rows, int32_t D, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes,
                           fc_stream stream);
+/* Gradient of `self.token_embedding(text)` (aligner/encoder/slip.py:469; what autograd's embedding backward does in
+ * teacher_student.py:99-140): d_table[id, :] (+)= the sum of d_rows[r, :] over the rows r with ids[r] == id, added IN ROW
+ * ORDER - a fixed-order segmented sum, no float atomics, so a step is bit-reproducible (SOT / EOT / pad ids collide in
+ * every caption).  ids dev int64 [rows] (clamped to the table like the forward gather), d_rows dev f32 [rows, D], d_table
+ * dev f32 [vocab, D]; rows of d_table whose id does not occur are left untouched (zero the table first unless
+ * accumulate = 1).  scratch: fc_token_embedding_backward_scratch_bytes(rows, vocab) bytes, 16-byte aligned. */
+FC_API size_t fc_token_embedding_backward_scratch_bytes(int32_t rows, int32_t vocab);
+FC_API int fc_token_embedding_backward(const int64_t* ids, const float* d_rows, float* d_table, int32_t rows, int32_t D,
+                                int32_t vocab, int32_t accumulate, void* scratch, size_t scratch_bytes, fc_stream stream);
 FC_API int fc_dot(const float* a, const float* b, size_t n, float alpha, float beta, float* out, fc_stream stream);
 FC_API int fc_transpose(const float* in, float* out, int32_t rows, int32_t cols, fc_stream stream);
 /* torch.optim.AdamW step `step` (counted from 1) over n floats (aligner/cli.py:129, config/trainer.yaml:21-23) */

@@ -31,6 +31,76 @@ def test_header_functions_are_exported_and_bound(lib_path):
     assert sorted(_lib.SIGNATURES) == names
 
 
+def _header_struct_fields(name):
+    text = (REPO / "include" / "fitclip_hip.h").read_text()
+    body = re.search(r"typedef struct \{(.*?)\} %s;" % name, text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    return re.findall(r"\b(int32_t|float|uint32_t|int64_t|size_t)\s+([a-zA-Z0-9_]+)\s*;", body)
+
+
+def test_documented_binding_matches_the_header_struct():
+    """INTEGRATION.md section 2 shows the reference-side ctypes stub.  Its FcConfig must list exactly the fields of the
+    header's fc_config, in order, and its constructor call must pass one value per field with sizeof first; the package's
+    own ctypes struct must agree too."""
+    from fitclip_amd import _lib
+    fields = _header_struct_fields("fc_config")
+    assert fields[0] == ("int32_t", "struct_size") and all(t == "int32_t" for t, _ in fields)
+    names = [n for _, n in fields]
+    assert [n for n, _ in _lib.fc_config._fields_] == names
+    assert ctypes.sizeof(_lib.fc_config) == 4 * len(names) and _lib.fc_config().struct_size == 4 * len(names)
+    doc = (REPO / "INTEGRATION.md").read_text()
+    stub = re.search(r"class FcConfig\(ctypes\.Structure\):.*?_fields_ = \[\(n, ctypes\.c_int32\) for n in \((.*?)\)\]", doc, flags=re.S)
+    assert stub, "INTEGRATION.md no longer shows the FcConfig stub"
+    documented = re.findall(r'"([a-z_0-9]+)"', re.sub(r"#.*", "", stub.group(1)))
+    assert documented == names
+    call = re.search(r"FcConfig\(ctypes\.sizeof\(FcConfig\),(.*?)\)\n", doc)
+    assert call, "the documented constructor call must start with ctypes.sizeof(FcConfig)"
+    assert len(call.group(1).split(",")) == len(names) - 1
+    version = re.search(r"#define FC_ABI_VERSION (\d+)", (REPO / "include" / "fitclip_hip.h").read_text()).group(1)
+    assert int(version) == _lib.ABI_VERSION and f"FC_ABI_VERSION {version}" in doc
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: the header must compile as C (no C++-isms), and FC_CONFIG_INIT must fill struct_size."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "fitclip_hip.h"\n'
+                   "int main(void) {\n  fc_config c = FC_CONFIG_INIT;\n  fc_handle* h = 0;\n"
+                   "  (void)h;\n  return c.struct_size == (int32_t)sizeof(fc_config) && c.embed_dim == 0 ? 0 : 1;\n}\n")
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", str(REPO / "include"), str(src)],
+                   check=True)
+    exe = tmp_path / "use_header"
+    subprocess.run([gcc, "-std=c99", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_fc_create_rejects_a_binding_of_another_struct_revision(lib_path):
+    """A caller compiled against an older fc_config (no struct_size; 15 or 16 int32 fields starting at embed_dim) or a future
+    one is refused before any field is interpreted - never read past its end."""
+    from fitclip_amd import _lib
+    lib = _lib.load()
+    assert lib.fc_version().endswith(b"abi %d" % _lib.ABI_VERSION)
+    create = ctypes.CDLL(str(lib_path)).fc_create
+    create.restype = ctypes.c_int32
+    h = ctypes.c_void_p()
+    values = [512, 224, 12, 768, 16, 77, 49408, 512, 8, 12, 0, 0, 0, 0, 0, 0]
+    for n in (15, 16):  # the two pre-guard layouts: the first int32 the library sees is embed_dim = 512
+        old = (ctypes.c_int32 * n)(*values[:n])
+        assert create(ctypes.byref(old), ctypes.byref(h)) == -1 and not h.value
+        msg = lib.fc_last_error()
+        assert b"struct_size is 512" in msg and b"%d bytes" % ctypes.sizeof(_lib.fc_config) in msg, msg
+    cfg = _lib.fc_config(*values)
+    cfg.struct_size += 4                                      # a later revision with one more field
+    assert lib.fc_create(cfg, h) == -1 and b"struct_size" in lib.fc_last_error()
+    cfg.struct_size -= 4
+    assert lib.fc_create(cfg, h) == 0
+    lib.fc_destroy(h)
+
+
 def test_error_reporting_without_gpu(lib_path):
     from fitclip_amd import _lib
     lib = _lib.load()

@@ -207,3 +207,33 @@ def test_quickgelu_is_accurate_per_element():
     big = ref.abs() > 1e-30
     assert float(rel[big].max()) < 4e-7, float(rel[big].max())
     assert float((out - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,D,vocab,pad_from", [(77, 64, 40, None), (1000, 512, 300, 5), (64 * 77, 512, 49408, 12),
+                                                  (3 * 1024 + 5, 128, 7, None), (1, 64, 3, None)])
+def test_token_embedding_backward_is_a_fixed_order_segmented_sum(rows, D, vocab, pad_from):
+    """Embedding backward of `token_embedding(text)` (slip.py:469): BITWISE the sequential float32 sum of the gradient rows of
+    each id in row order (numpy's unbuffered `np.add.at` is exactly that), for collision-heavy id patterns (SOT / EOT / pad
+    columns shared by every caption, segments longer than one 1024-row chunk), ids outside the table clamped like the
+    forward gather, `accumulate`, and two launches bit-identical."""
+    rng = np.random.default_rng(rows + vocab)
+    ids = rng.integers(0, vocab, size=rows, dtype=np.int64)
+    if pad_from is not None:  # caption shape: [SOT, tokens..., EOT, pad...] per 77-row sequence
+        pos = np.arange(rows) % 77
+        ids[pos == 0] = vocab - 2
+        ids[pos == pad_from] = vocab - 1
+        ids[pos > pad_from] = 0
+    if rows > 10:
+        ids[3], ids[7] = -5, vocab + 11  # clamped to 0 and vocab - 1
+    g = (rng.standard_normal((rows, D)) * np.exp(rng.uniform(-6, 6, size=(rows, 1)))).astype(np.float32)
+    want = np.zeros((vocab, D), np.float32)
+    np.add.at(want, np.clip(ids, 0, vocab - 1), g)
+    ids_d, g_d = torch.from_numpy(ids).to(DEV), torch.from_numpy(g).to(DEV)
+    got = ops.token_embedding_backward(ids_d, g_d, vocab)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert torch.equal(ops.token_embedding_backward(ids_d, g_d, vocab), got)
+    base = torch.from_numpy(rng.standard_normal((vocab, D)).astype(np.float32)).to(DEV)
+    acc = ops.token_embedding_backward(ids_d, g_d, vocab, out=base.clone(), accumulate=True)
+    touched = torch.from_numpy(np.bincount(np.clip(ids, 0, vocab - 1), minlength=vocab) > 0).to(DEV)
+    assert torch.equal(acc[~touched], base[~touched])
+    assert torch.equal(acc[touched], base[touched] + got[touched])

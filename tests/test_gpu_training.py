@@ -316,7 +316,7 @@ def test_training_step_at_one_ranks_share_of_config5(vitb16_state_dict):
     """BASELINE configs[4] per GPU: 64 clips x 8 frames through teacher + student ViT-B/16 and a full backward (60 GB of
     kept activations).  The CPU oracle cannot run this size; checked by properties: (i) the training forward returns,
     bit for bit, the embeddings of the inference path; (ii) the loss equals the forward-only module's; (iii) the
-    backward is deterministic (bit-identical gradients on a re-run, token-embedding atomics excepted); (iv) an AdamW
+    backward is deterministic (bit-identical gradients on a re-run); (iv) an AdamW
     step with lr = 0 and no weight decay leaves the model bit-identical, a real step changes every tensor."""
     from fitclip_amd.retrieval import TeacherStudentModule
     d = synth.VIT_B_16
@@ -342,12 +342,7 @@ def test_training_step_at_one_ranks_share_of_config5(vitb16_state_dict):
     assert torch.isfinite(grads1).all() and float(grads1.abs().max()) > 0
     module.training_step_end(module.training_step(batch))
     module.backward()
-    tok = module.student.offsets["token_embedding.weight"]
-    tok_n = d.vocab_size * d.transformer_width
-    same = module.student.grads == grads1
-    same[tok:tok + tok_n] = True
-    assert bool(same.all())
-    assert (module.student.grads[tok:tok + tok_n] - grads1[tok:tok + tok_n]).abs().max() <= 1e-5 * grads1[tok:tok + tok_n].abs().max()
+    assert torch.equal(module.student.grads, grads1)  # every sum of the step has a fixed order (no float atomics)
     before = module.student.params.clone()
     module.optimizer_step()                      # lr = 0, weight decay = 0: nothing may move
     assert torch.equal(module.student.params, before)
@@ -486,7 +481,7 @@ def test_predict_command_writes_the_embeddings(tmp_path, capsys):
 
 def test_checkpoint_and_resume_continue_the_same_run(tmp_path, tiny_state_dict):
     """Save after two steps, train two more; a FRESH trainer that loads the file and trains the same two steps ends with
-    the same weights, moments, temperatures and losses (the run is deterministic up to the token-embedding atomics).  The
+    BITWISE the same weights, moments, temperatures and losses (every sum of a step has a fixed order).  The
     file has the reference's module keys and a torch.optim.AdamW-shaped optimiser state."""
     d = synth.TINY
     student_np = synth.perturbed_state_dict(tiny_state_dict, d, seed=5, rel=0.3)
@@ -508,16 +503,10 @@ def test_checkpoint_and_resume_continue_the_same_run(tmp_path, tiny_state_dict):
     b.load_checkpoint(ckpt)
     assert b.student.step_count == 2 and b.student.lr == 1e-4 and abs(b.logit_scale - a.checkpoint()["state_dict"]["logit_scale"]) < 1
     losses_b = [b.fit_step(batch(step)) for step in range(2, 4)]
-    assert losses_b == pytest.approx(losses_a, rel=1e-5)
-    tok = a.student.offsets["token_embedding.weight"]
-    tok_n = d.vocab_size * d.transformer_width
+    assert losses_b == losses_a
     for buf in ("params", "exp_avg", "exp_avg_sq"):
-        x, y = getattr(a.student, buf), getattr(b.student, buf)
-        same = x == y
-        same[tok:tok + tok_n] = True
-        assert bool(same.all()), buf
-        assert (x[tok:tok + tok_n] - y[tok:tok + tok_n]).abs().max() <= 1e-5 * x[tok:tok + tok_n].abs().max() + 1e-9, buf
-    assert abs(a.logit_scale - b.logit_scale) < 1e-7 and abs(a.teacher_student_logit_scale - b.teacher_student_logit_scale) < 1e-7
+        assert torch.equal(getattr(a.student, buf), getattr(b.student, buf)), buf
+    assert a.logit_scale == b.logit_scale and a.teacher_student_logit_scale == b.teacher_student_logit_scale
     # evaluating the resumed student through the plain retrieval module ignores the teacher keys (text_video_retrieval.py:101-131)
     from fitclip_amd.retrieval import TextVideoRetrievalModule
     plain = TextVideoRetrievalModule(ClipVideoTextEncoder(build_clip(tiny_state_dict, precision="fp32", device=DEV)), init_temperature=0.05)
@@ -551,11 +540,7 @@ def test_teacher_skips_the_labeled_rows_without_changing_the_step(tiny_state_dic
         steps[literal] = (loss, dict(module.last_losses), module.student.grads.clone(), module.scale_grads.clone(), out)
     a, b = steps[True], steps[False]
     assert a[0] == b[0] and a[1] == b[1]
-    tok, tok_n = module.student.offsets["token_embedding.weight"], d.vocab_size * d.transformer_width
-    mask = torch.ones_like(a[2], dtype=torch.bool)  # the token-embedding gradient is an atomics-ordered sum
-    mask[tok:tok + tok_n] = False
-    assert torch.equal(a[2][mask], b[2][mask])
-    assert float((a[2] - b[2]).abs().max()) <= 1e-6 * float(a[2].abs().max())
+    assert torch.equal(a[2], b[2])
     assert torch.equal(a[3], b[3])
     assert torch.equal(a[4]["unlabeled"][1][0], b[4]["unlabeled"][1][0]) and torch.equal(a[4]["unlabeled"][1][1], b[4]["unlabeled"][1][1])
     assert not b[4]["labeled"][1][0].any() and not b[4]["labeled"][1][1].any() and a[4]["labeled"][1][0].any()

@@ -142,6 +142,35 @@ def test_bpe_tokenizer_matches_reference_fixture(golden_dir):
         assert out[6][:3].tolist() == [sot, eot, 0]  # empty text
 
 
+def test_decode_text_goes_through_the_bpe_decoder(golden_dir):
+    """`ClipVideoTextEncoder.decode_text` (clip_video_text_encoder.py:100-103) = `clip._tokenizer.decode(ids)` per row: every id,
+    SOT / EOT / padding included.  Rows tokenized by the plugin's own tokenizer decode to SOT + the reference's decoded
+    string (fixture) + EOT + the pad token's text repeated; the batch mapping and per-instance mappings give the same."""
+    from fitclip_amd import synth
+    from fitclip_amd.clip_model import CLIP
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+    from oracle.bpe_oracle import ClipBpeTokenizer as OracleBpe
+    g = json.loads((golden_dir / "bpe_toy.json").read_text())
+    path = str(golden_dir / "bpe_toy_merges.txt.gz")
+    enc = ClipVideoTextEncoder(CLIP(synth.TINY), bpe_path=path)
+    tokenizer = enc.get_tokenizer()
+    assert enc.get_tokenizer() is tokenizer                     # one native handle per encoder
+    L = enc.model.context_length
+    keep = [i for i, ids in enumerate(g["ids"]) if len(ids) + 2 <= L]
+    assert len(keep) >= 3
+    batch = tokenizer([g["texts"][i] for i in keep])
+    decoded = list(enc.decode_text(batch))
+    oracle = OracleBpe(path, context_length=L)
+    pad = oracle.decode([0])
+    for row, i, text in zip(batch["input_ids"], keep, decoded):
+        n_pad = L - 2 - len(g["ids"][i])
+        assert text == "<|startoftext|>" + g["decoded"][i] + "<|endoftext|>" + pad * n_pad
+        assert text == oracle.decode(row.tolist())
+    assert list(enc.decode_text([{"input_ids": row} for row in batch["input_ids"]])) == decoded
+    plain = ClipVideoTextEncoder(CLIP(synth.TINY))              # no vocabulary file: placeholders, padding dropped
+    assert next(plain.decode_text({"input_ids": torch.tensor([[5, 9, 0, 0]])})) == "<5> <9>"
+
+
 def test_bpe_tokenizer_at_full_vocabulary_size(golden_dir, tmp_path):
     """SURVEY 8(f) N2 at the real vocabulary size: a synthetic 48 894-merge file (regenerated from its seed; the
     published file is not available offline) -> SOT 49406 / EOT 49407, the 49152-256-2 cut, and ids identical to the
