@@ -9,9 +9,13 @@ Mirrors (behaviour, not code):
     `open-clip`, `apply-wise-ft` (file in, file out);
   * `aligner/text_video_retrieval.py:101-131` -> `load_module_state_dict`: a plain retrieval module silently drops the
     `teacher*` keys of a teacher-student checkpoint, and reports the other mismatches with torch's own wording;
-  * the module-level keys a Lightning checkpoint of the reference holds: `encoder.<param>`, `logit_scale`, and for the
-    distillation module `teacher.<param>`, `teacher_student_logit_scale` (`aligner/video_text_module.py:32`,
-    `aligner/teacher_student.py:55,70`).
+  * the module-level keys a Lightning checkpoint of the reference holds, in `nn.Module.state_dict()` order (a module's own
+    parameters first, then its children in registration order): `logit_scale`, `max_logit_scale` (both `nn.Parameter`s of
+    shape [1], `aligner/video_text_module.py:32-34`), for the distillation module `teacher_student_logit_scale`
+    (`aligner/teacher_student.py:70`), then `encoder.<param>`, `teacher.<param>` and, when the module was built with
+    `prompts`, `tokenized_prompts.input_ids` / `teacher_tokenized_prompts.input_ids` (`teacher_student.py:86-91`);
+  * `reference_parameter_order`: the index every parameter has in `torch.optim.AdamW(self.parameters())`
+    (`aligner/cli.py:129-132`), which is how `optimizer_states[0]["state"]` of a reference checkpoint is keyed.
 
 Only LOCAL paths are read (there is no egress; the reference's `cached_path(url)` fetch has no counterpart).  A path
 may be a pipe (process substitution), as in the reference's README recipes: it is drained into memory first because
@@ -77,6 +81,20 @@ def state_dict_from_checkpoint_path(checkpoint_path: TYPE_PATH, prefix: str = ""
     return strip_prefix(_load(checkpoint_path)["state_dict"], prefix)
 
 
+def trainable_parameter_indices(module: Any, fit_temperature: bool = True) -> "OrderedDict[int, str]":
+    """index -> key of the parameters that receive gradients (and therefore own an entry in the optimiser's `state`):
+    the two temperatures when they are fitted (video_text_module.py:32, teacher_student.py:70-71) and every encoder
+    parameter; the teacher is frozen (teacher_student.py:75-76)."""
+    out: "OrderedDict[int, str]" = OrderedDict()
+    for i, key in enumerate(reference_parameter_order(module)):
+        if key in ("logit_scale", "teacher_student_logit_scale"):
+            if fit_temperature:
+                out[i] = key
+        elif key.startswith("encoder."):
+            out[i] = key
+    return out
+
+
 # ------------------------------------------------------------------------------------------- module <-> state dict
 class IncompatibleKeys(NamedTuple):
     missing_keys: List[str]
@@ -84,21 +102,47 @@ class IncompatibleKeys(NamedTuple):
 
 
 def _scalar(v: float) -> torch.Tensor:
-    return torch.tensor(float(v))
+    return torch.tensor([float(v)])  # the reference's temperatures are nn.Parameters of shape [1]
+
+
+_PROMPT_KEYS = ("tokenized_prompts", "teacher_tokenized_prompts")  # nn.ParameterDicts of {"input_ids": [n, L]}
 
 
 def module_state_dict(module: Any) -> "OrderedDict[str, torch.Tensor]":
-    """The keys a Lightning checkpoint of the reference's module holds for the same object graph."""
+    """The keys, shapes and ORDER a Lightning checkpoint of the reference's module holds for the same object graph."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     sd["logit_scale"] = _scalar(module.logit_scale)
+    sd["max_logit_scale"] = _scalar(module.max_logit_scale)
+    teacher = getattr(module, "teacher", None)
+    if teacher is not None:
+        sd["teacher_student_logit_scale"] = _scalar(module.teacher_student_logit_scale)
     for k, v in module.encoder.state_dict().items():
         sd[f"encoder.{k}"] = v
-    teacher = getattr(module, "teacher", None)
     if teacher is not None:
         for k, v in teacher.state_dict().items():
             sd[f"teacher.{k}"] = v
-        sd["teacher_student_logit_scale"] = _scalar(module.teacher_student_logit_scale)
+        for attr in _PROMPT_KEYS:
+            ids = getattr(module, attr, None)
+            if ids is not None:
+                sd[f"{attr}.input_ids"] = ids
     return sd
+
+
+def reference_parameter_order(module: Any) -> List[str]:
+    """State-dict keys of everything `self.parameters()` yields on the reference's module, in that order - the order
+    `torch.optim.AdamW(self.parameters())` numbers them (cli.py:129-132): the module's own parameters (`logit_scale`,
+    `max_logit_scale`, `teacher_student_logit_scale`), then `encoder.*`, `teacher.*` and the prompt ids.  Frozen ones
+    (max_logit_scale, the teacher, the prompts; the temperatures with fit_temperature=False) are numbered too but
+    never get optimiser state."""
+    names = ["logit_scale", "max_logit_scale"]
+    teacher = getattr(module, "teacher", None)
+    if teacher is not None:
+        names.append("teacher_student_logit_scale")
+    names += [f"encoder.{k}" for k, _ in module.encoder.named_parameters()]
+    if teacher is not None:
+        names += [f"teacher.{k}" for k, _ in teacher.named_parameters()]
+        names += [f"{attr}.input_ids" for attr in _PROMPT_KEYS if getattr(module, attr, None) is not None]
+    return names
 
 
 def save_checkpoint(module: Any, path: TYPE_PATH, **extra: Any) -> None:
@@ -116,7 +160,9 @@ def load_module_state_dict(module: Any, state_dict: Mapping[str, torch.Tensor], 
     own = module_state_dict(module)
     has_teacher = getattr(module, "teacher", None) is not None
     unexpected = [k for k in state_dict if k not in own and (has_teacher or not k.startswith("teacher"))]
-    missing = [k for k in own if k not in state_dict]
+    # `max_logit_scale` is a constant the reference happens to store as a parameter: files written before this key
+    # was emitted (and bare `{"logit_scale", "encoder.*"}` dictionaries) stay loadable
+    missing = [k for k in own if k not in state_dict and k != "max_logit_scale"]
     if strict and (unexpected or missing):
         msgs = []
         if unexpected:
@@ -129,7 +175,9 @@ def load_module_state_dict(module: Any, state_dict: Mapping[str, torch.Tensor], 
         return {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix) and k in own}
 
     if "logit_scale" in state_dict:
-        module.logit_scale = float(state_dict["logit_scale"])
+        module.logit_scale = float(state_dict["logit_scale"])   # shape [1] in a reference file, 0-d accepted too
+    if "max_logit_scale" in state_dict:
+        module.max_logit_scale = float(state_dict["max_logit_scale"])
     enc = sub("encoder.")
     if enc:
         module.encoder.load_state_dict(enc, strict=False)
@@ -139,6 +187,10 @@ def load_module_state_dict(module: Any, state_dict: Mapping[str, torch.Tensor], 
             module.teacher.load_state_dict(tch, strict=False)
         if "teacher_student_logit_scale" in state_dict:
             module.teacher_student_logit_scale = float(state_dict["teacher_student_logit_scale"])
+        for attr in _PROMPT_KEYS:
+            key = f"{attr}.input_ids"
+            if key in state_dict and key in own:
+                setattr(module, attr, state_dict[key].to(getattr(module, attr).device).long())
     assert not math.isnan(module.logit_scale), "a checkpoint's module-level logit_scale is never NaN"
     return IncompatibleKeys(missing, unexpected)
 

@@ -398,46 +398,77 @@ class TeacherStudentTrainer(TeacherStudentModule):
         self.logit_scale, self.teacher_student_logit_scale = (float(x) for x in self.scales[:2].tolist())
 
     # ------------------------------------------------------------------------------------------ checkpoint / resume
+    def _optimizer_slots(self) -> List[Tuple[int, str, Any]]:
+        """(index, key, where) for every parameter that HAS optimiser state, numbered as the reference's
+        `AdamW(self.parameters())` numbers them (`checkpoint.trainable_parameter_indices`): `where` is a temperature slot
+        (0 / 1) or the encoder parameter's name in the flat buffers."""
+        from .checkpoint import trainable_parameter_indices
+        temps = {"logit_scale": 0, "teacher_student_logit_scale": 1}
+        prefix = "encoder.model."
+        return [(i, key, temps[key] if key in temps else key[len(prefix):])
+                for i, key in trainable_parameter_indices(self, self.fit_temperature).items()]
+
     def checkpoint(self) -> Dict[str, Any]:
-        """A Lightning-shaped training checkpoint: `state_dict` with the keys of the reference's module (`encoder.*`,
-        `teacher.*`, the two logit scales - what `fitclip_amd.checkpoint` and the reference's scripts read),
-        `optimizer_states[0]` in `torch.optim.AdamW.state_dict()` layout (index i = the i-th encoder parameter in
-        `named_parameters()` order, then the two temperatures) and `global_step`."""
-        from .checkpoint import module_state_dict
+        """A training checkpoint a reference run could resume from and vice versa: `state_dict` with the keys, shapes and
+        order of the reference module's Lightning checkpoint (`checkpoint.module_state_dict`: `logit_scale`,
+        `max_logit_scale`, `teacher_student_logit_scale` of shape [1], `encoder.*`, `teacher.*`, the prompt ids),
+        `optimizer_states[0]` in `torch.optim.AdamW.state_dict()` layout with the reference's parameter numbering
+        (`self.parameters()` order, cli.py:129-132; `state` entries only for the parameters that receive gradients) and
+        `global_step`."""
+        from .checkpoint import module_state_dict, reference_parameter_order
         s = self.student
         state = {}
-        for i, (name, p) in enumerate(s.model._named_weights()):
-            o, n = s.offsets[name], p.numel()
-            state[i] = {"step": torch.tensor(float(s.step_count)), "exp_avg": s.exp_avg[o:o + n].view(p.shape).cpu(),
-                        "exp_avg_sq": s.exp_avg_sq[o:o + n].view(p.shape).cpu()}
-        n_enc = len(state)
-        for j in range(2):
-            state[n_enc + j] = {"step": torch.tensor(float(s.step_count)), "exp_avg": self.scale_m[j].cpu(),
-                                "exp_avg_sq": self.scale_v[j].cpu()}
+        step = torch.tensor(float(s.step_count))
+        for i, _, where in self._optimizer_slots():
+            if isinstance(where, int):
+                state[i] = {"step": step.clone(), "exp_avg": self.scale_m[where:where + 1].cpu(),
+                            "exp_avg_sq": self.scale_v[where:where + 1].cpu()}
+            else:
+                o, shape = s.offsets[where], dict(s.model._named_weights())[where].shape
+                n = int(torch.Size(shape).numel())
+                state[i] = {"step": step.clone(), "exp_avg": s.exp_avg[o:o + n].view(shape).cpu(),
+                            "exp_avg_sq": s.exp_avg_sq[o:o + n].view(shape).cpu()}
         group = {"lr": s.lr, "betas": s.betas, "eps": s.eps, "weight_decay": s.weight_decay, "amsgrad": False,
-                 "maximize": False, "params": list(range(n_enc + 2))}
+                 "maximize": False, "params": list(range(len(reference_parameter_order(self))))}
         return {"state_dict": {k: v.detach().cpu() for k, v in module_state_dict(self).items()},  # host tensors
                 "optimizer_states": [{"state": state, "param_groups": [group]}], "global_step": s.step_count}
 
     def load_checkpoint(self, ckpt: Mapping[str, Any]) -> None:
-        """Resumes from `checkpoint()`: weights, AdamW moments, step count and temperatures; the next `fit_step`
-        continues exactly where the saved run would have."""
-        from .checkpoint import load_module_state_dict
+        """Resumes from `checkpoint()` (or a reference Lightning checkpoint of the same module graph): weights, AdamW
+        moments, step count and temperatures; every sum of a step has a fixed order, so the next `fit_step` continues
+        bit-for-bit where the saved run would have."""
+        from .checkpoint import load_module_state_dict, reference_parameter_order
         s = self.student
         load_module_state_dict(self, ckpt["state_dict"], strict=True)     # copies into the flat parameter buffer (views)
         self.scales[0], self.scales[1] = self.logit_scale, self.teacher_student_logit_scale
         opt = ckpt["optimizer_states"][0]
-        named = s.model._named_weights()
-        with torch.no_grad():
-            for i, (name, p) in enumerate(named):
-                o, n = s.offsets[name], p.numel()
-                s.exp_avg[o:o + n].view(p.shape).copy_(opt["state"][i]["exp_avg"])
-                s.exp_avg_sq[o:o + n].view(p.shape).copy_(opt["state"][i]["exp_avg_sq"])
-            for j in range(2):
-                self.scale_m[j] = opt["state"][len(named) + j]["exp_avg"]
-                self.scale_v[j] = opt["state"][len(named) + j]["exp_avg_sq"]
-        s.step_count = int(ckpt["global_step"])
         g = opt["param_groups"][0]
+        n_params = len(reference_parameter_order(self))
+        if len(g["params"]) != n_params:
+            raise ValueError(f"the checkpoint's optimiser numbers {len(g['params'])} parameters, this module has {n_params} "
+                             "(logit scales, encoder, teacher, prompts): not a checkpoint of the same module graph")
+        shapes = dict(s.model._named_weights())
+        with torch.no_grad():
+            for i, key, where in self._optimizer_slots():
+                entry = opt["state"].get(i)
+                if entry is None:                                   # saved before this parameter's first gradient
+                    m = v = None
+                else:
+                    m, v = entry["exp_avg"], entry["exp_avg_sq"]
+                if isinstance(where, int):
+                    self.scale_m[where] = 0.0 if m is None else float(m)
+                    self.scale_v[where] = 0.0 if v is None else float(v)
+                    continue
+                o, shape = s.offsets[where], shapes[where].shape
+                n = int(torch.Size(shape).numel())
+                for buf, src in ((s.exp_avg, m), (s.exp_avg_sq, v)):
+                    if src is None:
+                        buf[o:o + n].zero_()
+                    else:
+                        if tuple(src.shape) != tuple(shape):
+                            raise ValueError(f"optimiser state {i} ({key}) has shape {tuple(src.shape)}, expected {tuple(shape)}")
+                        buf[o:o + n].view(shape).copy_(src)
+        s.step_count = int(ckpt["global_step"])
         s.lr, s.betas, s.eps, s.weight_decay = float(g["lr"]), tuple(map(float, g["betas"])), float(g["eps"]), float(g["weight_decay"])
         s.rebind()
 

@@ -166,3 +166,78 @@ def test_open_clip_checkpoint_conversion(tmp_path):
     torch.save({"state_dict": {"encoder.x": torch.zeros(1)}}, bad)
     with pytest.raises(StopIteration):
         C.open_clip_checkpoint_to_model(bad, tmp_path / "never.pt")
+
+
+def _reference_shaped_module(encoder, teacher, prompt_ids=None, fit_temperature=True):
+    """A torch `nn.Module` whose attributes are registered in the order the reference's constructors register them
+    (`VideoTextLightningModule.__init__`, video_text_module.py:28-35: encoder, logit_scale, max_logit_scale, loss;
+    `TeacherStudentLightningModule.__init__`, teacher_student.py:52-91: teacher, teacher_student_logit_scale, frozen
+    teacher, the two prompt `nn.ParameterDict`s) - so `state_dict()`, `parameters()` and `torch.optim.AdamW(parameters())`
+    give the key order, shapes and parameter numbering of a reference checkpoint.  (The Lightning classes themselves are
+    not importable here; nothing of them is copied - only the registration order is restated.)"""
+    from torch import nn
+
+    class ReferenceShaped(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = encoder
+            for p in self.encoder.parameters():   # a `clip.load`ed model is trainable (this repo's CLIP holds plain buffers-
+                p.requires_grad = True            # like parameters: the HIP trainer owns the gradients)
+            self.logit_scale = nn.Parameter(torch.tensor([-math.log(0.05)]), requires_grad=fit_temperature)
+            self.max_logit_scale = nn.Parameter(torch.tensor([-math.log(0.001)]), requires_grad=False)
+            self.loss = nn.Identity()
+            self.metrics = nn.ModuleDict()
+            self.teacher = teacher
+            self.teacher_student_logit_scale = nn.Parameter(self.logit_scale.clone(), requires_grad=fit_temperature)
+            self.teacher_student_loss = nn.Identity()
+            for p in self.teacher.parameters():
+                p.requires_grad = False
+            if prompt_ids is not None:
+                self.tokenized_prompts = nn.ParameterDict({"input_ids": nn.Parameter(prompt_ids, requires_grad=False)})
+                self.teacher_tokenized_prompts = nn.ParameterDict({"input_ids": nn.Parameter(prompt_ids.clone(), requires_grad=False)})
+
+    return ReferenceShaped()
+
+
+@pytest.mark.parametrize("with_prompts,fit_temperature", [(False, True), (True, True), (False, False)])
+def test_checkpoint_layout_is_the_reference_modules(with_prompts, fit_temperature):
+    """`module_state_dict` / `reference_parameter_order` / `trainable_parameter_indices` against torch's own bookkeeping on a
+    module with the reference's registration order: same state-dict keys in the same order with the same shapes, the same
+    `parameters()` numbering, and optimiser `state` entries for exactly the parameters torch.optim.AdamW creates them for.
+    And the other direction: a state dict of that module loads (strict) into this repo's module."""
+    prompt_ids = torch.arange(3 * synth.TINY.context_length).view(3, -1) % 7 if with_prompts else None
+    ref = _reference_shaped_module(_encoder(21), _encoder(22), prompt_ids, fit_temperature)
+    ours = TeacherStudentModule(_encoder(23), _encoder(24), init_temperature=0.3)
+    if with_prompts:
+        ours.tokenized_prompts, ours.teacher_tokenized_prompts = prompt_ids + 1, prompt_ids + 1
+    ref_sd = ref.state_dict()
+    sd = C.module_state_dict(ours)
+    assert list(sd) == list(ref_sd)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v.shape) for k, v in ref_sd.items()}
+    assert "encoder.model.logit_scale" not in sd and tuple(sd["logit_scale"].shape) == (1,)
+    assert C.reference_parameter_order(ours) == [n for n, _ in ref.named_parameters()]
+
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    sum((p.float() ** 2).sum() for p in ref.parameters() if p.requires_grad).backward()
+    opt.step()
+    opt_sd = opt.state_dict()
+    indices = C.trainable_parameter_indices(ours, fit_temperature)
+    assert sorted(opt_sd["state"]) == list(indices)
+    assert opt_sd["param_groups"][0]["params"] == list(range(len(C.reference_parameter_order(ours))))
+    names = [n for n, _ in ref.named_parameters()]
+    assert all(names[i] == key for i, key in indices.items())
+
+    res = C.load_module_state_dict(ours, ref_sd, strict=True)
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    assert ours.logit_scale == pytest.approx(float(ref.logit_scale)) and ours.max_logit_scale == pytest.approx(-math.log(0.001))
+    _same(ours.encoder.state_dict(), ref.encoder.state_dict())
+    _same(ours.teacher.state_dict(), ref.teacher.state_dict())
+    if with_prompts:
+        assert torch.equal(ours.tokenized_prompts, prompt_ids) and torch.equal(ours.teacher_tokenized_prompts, prompt_ids)
+    else:  # a module built without prompts rejects a checkpoint that has them, as nn.Module.load_state_dict does
+        extra = dict(ref_sd)
+        extra["tokenized_prompts.input_ids"] = torch.zeros(2, 4)
+        with pytest.raises(RuntimeError, match='Unexpected key.*tokenized_prompts.input_ids'):
+            C.load_module_state_dict(ours, extra, strict=True)
+    # and the reference module accepts what this repo writes
+    ref.load_state_dict(C.module_state_dict(ours), strict=True)

@@ -498,7 +498,17 @@ def test_checkpoint_and_resume_continue_the_same_run(tmp_path, tiny_state_dict):
     ckpt = torch.load(path, weights_only=True)   # tensors and plain containers only
     assert {"state_dict", "optimizer_states", "global_step"} <= set(ckpt) and ckpt["global_step"] == 2
     assert "encoder.model.visual.proj" in ckpt["state_dict"] and "teacher.model.visual.proj" in ckpt["state_dict"]
-    assert set(ckpt["optimizer_states"][0]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    opt_state = ckpt["optimizer_states"][0]["state"]
+    assert set(opt_state[0]) == {"step", "exp_avg", "exp_avg_sq"}
+    # the reference's numbering (AdamW(self.parameters()), cli.py:129): 0 logit_scale, 1 max_logit_scale (frozen: no state),
+    # 2 teacher_student_logit_scale, 3... the encoder's parameters, then the frozen teacher's (no state)
+    from fitclip_amd.checkpoint import reference_parameter_order
+    order = reference_parameter_order(a)
+    assert order[:4] == ["logit_scale", "max_logit_scale", "teacher_student_logit_scale", "encoder.model.positional_embedding"]
+    assert sorted(opt_state) == [i for i, k in enumerate(order) if k != "max_logit_scale" and not k.startswith("teacher.")]
+    assert opt_state[3]["exp_avg"].shape == ckpt["state_dict"]["encoder.model.positional_embedding"].shape
+    assert tuple(ckpt["state_dict"]["logit_scale"].shape) == (1,) and "max_logit_scale" in ckpt["state_dict"]
+    assert ckpt["optimizer_states"][0]["param_groups"][0]["params"] == list(range(len(order)))
     b = _trainer(tiny_state_dict, tiny_state_dict, 0.3, lr=7.0)       # wrong weights, temperature and lr: all come from the file
     b.load_checkpoint(ckpt)
     assert b.student.step_count == 2 and b.student.lr == 1e-4 and abs(b.logit_scale - a.checkpoint()["state_dict"]["logit_scale"]) < 1
