@@ -10,7 +10,18 @@ One step = one pass of the hot path over one batch of synthetic input, inputs al
   encode_video(256 clips x 8 frames x 3 x 224 x 224 fp32)  +  encode_text(256 x 77 ids)   (CLIP ViT-B/16, random init)
   -> [all-gather of the embeddings over RCCL when N > 1] -> T @ V^T -> rank of every caption's clip.
 Per-GPU work is fixed as N grows (each rank encodes its own 256 clips): "scaling": "weak"; `value` is whole-job
-pairs/s = N * 256 / (max over ranks of the step time).
+pairs/s = N * 256 / (max over ranks of the step time).  That is `--config c2` (BASELINE configs[1]), the default and the
+driver's line.  The two multi-GPU configurations BASELINE names run through the same command:
+  --config c4   configs[3]: 8192 clips x 16 frames + 8192 texts IN TOTAL, exact contiguous clip shards over the N ranks (ragged
+                when N does not divide 8192), each rank encodes its shard in eval batches, ONE all-gather of the
+                [n_local, 512] embeddings, row-block scoring, int32 ranks gathered: "scaling": "strong"
+  --config c5   configs[4]: the distillation training step (teacher + student dual forward, NCE + KD losses, student
+                backward, AdamW) on 512 clips x 8 frames IN TOTAL, half labeled on every rank; one packed all-gather of the
+                four embedding matrices + three gradient all-reduces per step: "scaling": "strong"
+  (--total-clips / --frames / --eval-batch shrink them for rehearsals.)
+With more than one rank only the headline leg runs (secondary legs would multiply the collectives of one driver
+command); `--all-legs` restores them.  A failing secondary leg is reported under its key, the headline line is still
+printed, and the process exits non-zero; after a HIP runtime error no further GPU leg is started.
 
 HEADLINE = the reference's precision: every GEMM / attention product on the fp32-input matrix cores
 (`v_mfma_f32_16x16x4_f32`, peak 157.3 TFLOP/s), fp32 everywhere else ("dtype": "fp32"; the reference loads CLIP in
@@ -20,8 +31,10 @@ its Recall deltas; it never is `value`.
 
 The same JSON line carries
   * "roofline": the dominant kernel (the MFMA GEMM instantiation with the largest total time), its average launch
-    duration measured with hipEvent pairs recorded by the library on the stream the kernels run on, inside the timed
-    region (only that kernel is instrumented there: an event pair serialises dispatch for a few microseconds);
+    duration measured with hipEvent pairs recorded by the library on the stream the kernels run on.  The timed region
+    itself carries NO instrumentation (`value` pays no profiler tax): the same K steps are repeated right after it with
+    event pairs around the four big GEMMs of every block, and that repetition's wall time is reported next to the
+    timed one ("instrumented_repeat_ms_per_step");
     achieved = algorithmic FLOPs per launch / that duration; peak = dense MFMA peak of the dtype (MI355X_MICROARCH.md);
     traffic = HBM bytes per launch from the PMC passes of tools/profile_round.sh, accepted only if the pass was made
     with the SAME kernel sources (fingerprint of fitclip_amd/csrc + include), else null.
@@ -188,7 +201,7 @@ def load_traffic(precision, shape, epilogue):
     the ones in this tree is refused."""
     from fitclip_amd.build import source_fingerprint
     fp = source_fingerprint()
-    for name in (f"traffic_r02_{precision}.json",):
+    for name in (f"traffic_r03_{precision}.json", f"traffic_r02_{precision}.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -248,26 +261,44 @@ def training_leg(sd, video, ids, args, dims, device, clips=64, steps=2):
     return out
 
 
-def run_mode(precision, sd, video, text, args, world, rank, device, backend, full_detail):
-    """Warm-up, the timed K steps, and (untimed) the instrumented step + visual-tower passes for one precision."""
-    import torch.distributed as dist
+class Shards:
+    """Which clips this rank holds: `counts[r]` clips on rank r (contiguous, exact - `distributed.shard_counts`), `offset` = the
+    global index of this rank's first clip, `eval_batch` = clips per encoder call (None: the whole shard in one call)."""
+
+    def __init__(self, counts, rank, eval_batch=None):
+        self.counts, self.rank = list(counts), rank
+        self.n_local, self.n_total, self.offset = counts[rank], sum(counts), sum(counts[:rank])
+        self.eval_batch = eval_batch if eval_batch and eval_batch < self.n_local else None
+
+
+def make_step(enc, video, text, shards):
+    """One pass of the hot path over this rank's shard: encode (in eval batches when the shard is larger than one), ONE
+    all-gather of the video embeddings, the rank's row block of T @ V^T, ranks, all-gather of the int32 ranks."""
     from fitclip_amd import distributed as D
     from fitclip_amd import ops
-    from fitclip_amd.clip_model import build_clip
-    from fitclip_amd.encoder import ClipVideoTextEncoder
+    ids = text["input_ids"]
 
-    enc = ClipVideoTextEncoder(build_clip(sd, precision=precision, device=device, chunk_frames=args.chunk_frames,
-                                          gemm_tile=args.gemm_tile, prune_last_block=args.prune_last_block),
-                               num_frames=args.frames)
-    n_local = args.clips
-    counts = [n_local] * world
+    def encode():
+        if shards.eval_batch is None:
+            return enc(video=video, text=text)
+        parts = [enc(video=video[s:s + shards.eval_batch], text={"input_ids": ids[s:s + shards.eval_batch]})
+                 for s in range(0, shards.n_local, shards.eval_batch)]
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
 
     def step():
-        ev, et = enc(video=video, text=text)
-        all_v = D.all_gather_rows(ev, counts)
+        ev, et = encode()
+        all_v = D.all_gather_rows(ev, shards.counts)
         scores = ops.similarity(et, all_v)
-        ranks = ops.ranks(scores, rank * n_local)
-        return ev, et, D.all_gather_rows(ranks, counts)
+        ranks = ops.ranks(scores, shards.offset)
+        return ev, et, D.all_gather_rows(ranks, shards.counts)
+
+    return step
+
+
+def timed_steps(step, steps, device, backend):
+    """EXACTLY `steps` steps between barrier + synchronize fences; returns (max over ranks of the wall time, last outputs)."""
+    import torch.distributed as dist
+    from fitclip_amd import distributed as D
 
     def fence():
         torch.cuda.synchronize()
@@ -275,25 +306,41 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = None
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if D.collectives_active():
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    return float(elapsed), out
+
+
+def run_mode(precision, sd, video, text, args, shards, device, backend, full_detail):
+    """Warm-up, the timed K steps (uninstrumented), and - untimed - the same K steps with event pairs around the four big
+    block GEMMs, one fully instrumented step and the visual-tower passes, for one precision."""
+    from fitclip_amd.clip_model import build_clip
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+
+    enc = ClipVideoTextEncoder(build_clip(sd, precision=precision, device=device, chunk_frames=args.chunk_frames,
+                                          gemm_tile=args.gemm_tile, prune_last_block=args.prune_last_block),
+                               num_frames=args.frames)
+    n_local = shards.n_local
+    step = make_step(enc, video, text, shards)
     for _ in range(args.warmup):
         step()
-    # Timed region: hipEvent pairs only around the four big GEMMs of every block (the two store epilogues: c_fc+QuickGELU
-    # and the bias GEMMs QKV / out_proj / c_proj; c_fc and c_proj are within 2 % of each other, so either can be the
-    # dominant one); an event pair serialises dispatch for a few microseconds, so the other ~300 launches of a step are
-    # not instrumented here.  Which kernel dominates is decided by the fully instrumented, UNTIMED step that follows.
+    elapsed, (ev, et, all_ranks) = timed_steps(step, args.steps, device, backend)
+    # After the timed region: the same K steps once more with hipEvent pairs around the four big GEMMs of every block (the
+    # two store epilogues: c_fc+QuickGELU and the bias GEMMs QKV / out_proj / c_proj; c_fc and c_proj are within 2 % of each
+    # other, so either can be the dominant one).  An event pair serialises dispatch for a few microseconds; the other ~300
+    # launches of a step stay uninstrumented here, so this repetition runs within a fraction of a percent of the timed one
+    # (both wall times are reported).  Which kernel dominates is decided by the fully instrumented step that follows.
     enc.model.profile(16384)
     enc.model.profile_select(kind_mask=1, epilogue_mask=(1 << EPI_GELU) | (1 << EPI_BIAS))
     enc.model.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ev, et, all_ranks = step()
-    fence()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                           device=device if backend == "nccl" else "cpu")
-    if D.collectives_active():
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed)
+    repeat_elapsed, _ = timed_steps(step, args.steps, device, backend)
     timed_records = enc.model.profile_records()
     enc.model.profile_select()
     enc.model.profile_reset()
@@ -307,10 +354,11 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
     records = enc.model.profile_records()
     enc.model.profile(0)
     # ViT forward alone: the visual tower + pooling over the same frames, uninstrumented, untimed part
-    fence()
+    vit_clips = min(n_local, shards.eval_batch or n_local)
+    torch.cuda.synchronize()
     t2 = time.perf_counter()
     for _ in range(args.steps):
-        enc.encode_video(video)
+        enc.encode_video(video[:vit_clips])
     torch.cuda.synchronize()
     vit_elapsed = time.perf_counter() - t2
 
@@ -321,7 +369,8 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
     timed_by_kernel, _ = aggregate(timed_records)
     if dom_key in timed_by_kernel:
         ms, cnt, flops = timed_by_kernel[dom_key]
-        timing_source, ref_elapsed_ms = "hipEvent pairs inside the timed region", elapsed * 1e3
+        timing_source, ref_elapsed_ms = ("hipEvent pairs around the four big block GEMMs while the K timed steps are repeated "
+                                         "right after the (uninstrumented) timed region"), repeat_elapsed * 1e3
     else:  # the dominant kernel is not the one instrumented in the timed region (other shape)
         ms, cnt, flops = by_kernel[dom_key]
         timing_source, ref_elapsed_ms = "hipEvent pairs in the instrumented extra step", split_elapsed * 1e3
@@ -335,18 +384,19 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
                 "traffic": traffic, "traffic_note": traffic_note, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
                 "flops_per_launch": flops / cnt, "timing": timing_source,
                 "share_of_step_time": round(ms / ref_elapsed_ms, 4)}
-    step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
+    step_flops = max(shards.counts) * (args.frames * GF_PER_FRAME + GF_PER_TEXT)  # the largest shard sets the step time
     all_gemms = {"achieved": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                  "frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak, 4),
                  "share_of_step_time": round(gemm_ms / (split_elapsed * 1e3), 4),
                  "timing": "instrumented extra step (every launch carries an event pair)"}
     whole_path = {"achieved": round(step_flops * args.steps / elapsed / 1e12, 2), "unit": "TFLOP/s",
                   "frac": round(step_flops * args.steps / elapsed / 1e12 / peak, 4)}
-    vit_tf = n_local * args.frames * GF_PER_FRAME * args.steps / vit_elapsed / 1e12
+    vit_tf = vit_clips * args.frames * GF_PER_FRAME * args.steps / vit_elapsed / 1e12
     vit_forward = {"achieved": round(vit_tf, 2), "unit": "TFLOP/s", "frac": round(vit_tf / peak, 4),
                    "ms_per_pass": round(vit_elapsed / args.steps * 1e3, 3),
-                   "frames": n_local * args.frames, "note": "rank-local encode_video only, after the timed region"}
-    out = {"value": round(n_local * world * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                   "frames": vit_clips * args.frames, "note": "rank-local encode_video only, after the timed region"}
+    out = {"value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "instrumented_repeat_ms_per_step": round(repeat_elapsed / args.steps * 1e3, 3),
            "dtype": precision, "roofline": roofline, "roofline_all_gemms": all_gemms, "roofline_whole_path": whole_path,
            "roofline_vit_forward": vit_forward}
     if full_detail:
@@ -357,43 +407,20 @@ def run_mode(precision, sd, video, text, args, world, rank, device, backend, ful
     return out, (ev, et, all_ranks)
 
 
-def run_split_mode(sd, video, text, args, world, rank, device, backend):
+def run_split_mode(sd, video, text, args, shards, device, backend):
     """Secondary leg `fp32_split_mode` (precision "fp32x6"): the same step with the visual tower's block GEMMs on the bf16
     matrix cores over split-fp32 operands (three bf16 numbers per value, six bf16 products per fp32 product, fp32
     accumulate) - fp32 accuracy from the pipe that is 16x faster than the fp32-input one.  Timed like the headline; the
     per-kernel figures come from one instrumented extra step."""
-    import torch.distributed as dist
-    from fitclip_amd import distributed as D
-    from fitclip_amd import ops
     from fitclip_amd.clip_model import build_clip
     from fitclip_amd.encoder import ClipVideoTextEncoder
 
     enc = ClipVideoTextEncoder(build_clip(sd, precision="fp32x6", device=device), num_frames=args.frames)
-    n_local = args.clips
-    counts = [n_local] * world
-
-    def step():
-        ev, et = enc(video=video, text=text)
-        scores = ops.similarity(et, D.all_gather_rows(ev, counts))
-        return ev, et, D.all_gather_rows(ops.ranks(scores, rank * n_local), counts)
-
-    def fence():
-        torch.cuda.synchronize()
-        if D.collectives_active():
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    n_local = shards.n_local
+    step = make_step(enc, video, text, shards)
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ev, et, all_ranks = step()
-    fence()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if D.collectives_active():
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed)
+    elapsed, (ev, et, all_ranks) = timed_steps(step, args.steps, device, backend)
     enc.model.profile(16384)
     enc.model.profile_reset()
     overlap, enc.overlap_text = enc.overlap_text, False
@@ -418,7 +445,7 @@ def run_split_mode(sd, video, text, args, world, rank, device, backend):
     step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
     other = aggregate(records)[1]
     return {
-        "value": round(n_local * world * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate; LayerNorm, "
                  "softmax, residual stream, patch embedding and the text tower in plain fp32",
         "roofline": {"bound": "mfma", "kernel": f"gemm_pipelined_kernel<256x256><bf16 six-plane operands,"
@@ -439,19 +466,92 @@ def run_split_mode(sd, video, text, args, world, rank, device, backend):
     }, (ev, et, all_ranks)
 
 
-def guarded(result, key, world, fn):
-    """Secondary legs must not cost the headline line: on ONE rank a failing leg is reported under its key and the run goes
-    on (with more ranks an exception propagates - a rank that skipped the leg's collectives would hang the others)."""
-    if world > 1:
-        return fn()
-    try:
-        return fn()
-    except Exception as e:  # noqa: BLE001
-        import traceback
-        traceback.print_exc(file=sys.stderr)
-        result[key] = {"error": f"{type(e).__name__}: {e}"}
-        torch.cuda.empty_cache()
-        return None
+class Legs:
+    """Secondary legs must not cost the headline line.  On ONE rank a failing leg is reported under its key, the run goes on
+    and the process exits non-zero at the end; after a HIP RUNTIME error (a launch failure or fault, as opposed to a
+    Python-level assertion) no further GPU leg is started on the possibly poisoned context.  With more ranks an exception
+    propagates: the rank exits non-zero and torch.distributed.run stops its peers (a rank that merely skipped the leg's
+    collectives would hang the others)."""
+
+    def __init__(self, result, world):
+        self.result, self.world, self.failed, self.gpu_poisoned = result, world, [], False
+
+    @staticmethod
+    def _is_hip_runtime_error(e) -> bool:
+        text = f"{type(e).__name__}: {e}"
+        return ("(-2)" in text and "libfitclip_hip" in text or "fc_" in text and "(-2)" in text or "HIP error" in text
+                or "hipError" in text or type(e).__name__ == "AcceleratorError")
+
+    def run(self, key, fn, uses_gpu=True):
+        if uses_gpu and self.gpu_poisoned:
+            self.result[key] = {"skipped": "an earlier leg ended in a HIP runtime error"}
+            return None
+        if self.world > 1:
+            return fn()
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            self.result[key] = {"error": f"{type(e).__name__}: {e}"}
+            self.failed.append(key)
+            if self._is_hip_runtime_error(e):
+                self.gpu_poisoned = True
+            else:
+                torch.cuda.empty_cache()
+            return None
+
+
+CONFIG_DEFAULTS = {  # BASELINE.json `configs`: index, clips, frames, scaling
+    "c2": {"baseline_index": 1, "frames": 8, "scaling": "weak"},
+    "c4": {"baseline_index": 3, "total_clips": 8192, "frames": 16, "scaling": "strong", "eval_batch": 128},
+    "c5": {"baseline_index": 4, "total_clips": 512, "frames": 8, "scaling": "strong"},
+}
+
+
+def fill_video(n_clips, frames, res, seed, device, block=256):
+    """`synth_video_on_device` in blocks of clips (the generator's temporaries stay small next to a 79 GB shard)."""
+    out = torch.empty((n_clips, frames, 3, res, res), dtype=torch.float32, device=device)
+    for s in range(0, n_clips, block):
+        n = min(block, n_clips - s)
+        out[s:s + n] = synth_video_on_device(n, frames, res, seed=seed * 7919 + s, device=device)
+    return out
+
+
+def run_kd_config(sd, dims, args, shards, device, backend):
+    """`--config c5` (BASELINE configs[4]): the distillation training step of `TeacherStudentLightningModule`
+    (aligner/teacher_student.py:93-183) on `total_clips` clips x `frames` frames sharded over the ranks, half of every rank's
+    rows labeled: student forward with kept activations + frozen teacher forward, the packed all-gather of the four embedding
+    matrices, NCE + KD losses over the full batch, student backward, three gradient all-reduces, AdamW.  One step = one
+    `fit_step`; FLOPs = 3 x the student's forward + the teacher's forward over the unlabeled half."""
+    from fitclip_amd import synth
+    from fitclip_amd.clip_model import build_clip
+    from fitclip_amd.encoder import ClipVideoTextEncoder
+    from fitclip_amd.training import TeacherStudentTrainer
+    n, frames = shards.n_local, args.frames
+    if n < 2:
+        raise SystemExit(f"--config c5: rank {shards.rank} holds {n} clip(s); every rank needs a labeled and an unlabeled row")
+    video = fill_video(n, frames, dims.image_resolution, seed=1000 + shards.rank, device=device)
+    ids = torch.from_numpy(synth.make_text(n, dims, seed=42, first_text=shards.offset)).to(device)
+    student = ClipVideoTextEncoder(build_clip(synth.perturbed_state_dict(sd, dims, seed=5, rel=0.05), precision="fp32",
+                                              device=device), num_frames=frames)
+    teacher = ClipVideoTextEncoder(build_clip(sd, precision="fp32", device=device), num_frames=frames)
+    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=3e-7)
+    n_lab = n // 2
+    batch = {"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
+             "text_teacher": {"input_ids": ids}, "dataset": ["labeled"] * n_lab + ["unlabeled"] * (n - n_lab)}
+    losses = [module.fit_step(batch) for _ in range(args.warmup)]
+    elapsed, last = timed_steps(lambda: losses.append(module.fit_step(batch)), args.steps, device, backend)
+    n_big = max(shards.counts)
+    flops = 3.0 * n_big * (frames * GF_PER_FRAME + GF_PER_TEXT) + (n_big - n_big // 2) * (frames * GF_PER_FRAME + GF_PER_TEXT)
+    tf = flops * args.steps / elapsed / 1e12
+    return {"value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "roofline": {"bound": "mfma", "kernel": "whole training step of the largest shard (forward, dgrad, wgrad, teacher forward)",
+                         "achieved": round(tf, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_TFLOPS["fp32"], 4), "traffic": None,
+                         "flops_per_step": flops, "timing": "wall time of the timed region, max over ranks"},
+            "losses": [round(float(x), 6) for x in losses],
+            "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
 def main() -> None:
@@ -459,12 +559,20 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIG_DEFAULTS),
+                    help="c2 = BASELINE configs[1] (default; weak scaling, 256 clips x 8 frames per GPU); c4 = configs[3] "
+                         "(8192 clips x 16 frames in total, sharded; strong); c5 = configs[4] (512 x 8 teacher+student KD "
+                         "training step in total, sharded; strong)")
+    ap.add_argument("--total-clips", type=int, default=None, help="c4 / c5: clips over ALL ranks (default 8192 / 512)")
+    ap.add_argument("--eval-batch", type=int, default=None, help="c4: clips per encoder call (default 128)")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="with more than one rank, also run the secondary legs (bf16_mode, fp32_split_mode); default: headline only")
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"],
                     help="headline precision; fp32 = the reference's (default).  bf16 here is for kernel work only")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-operand run")
     ap.add_argument("--no-split-mode", action="store_true", help="skip the secondary split-fp32 run (fp32_split_mode)")
-    ap.add_argument("--clips", type=int, default=256, help="clips (= captions) per GPU per step")
-    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--clips", type=int, default=256, help="c2: clips (= captions) per GPU per step")
+    ap.add_argument("--frames", type=int, default=None, help="frames per clip (default 8; c4: 16)")
     ap.add_argument("--chunk-frames", type=int, default=0)
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=32)
@@ -478,6 +586,9 @@ def main() -> None:
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: no GPU work, rank 0 prints {world, sum of ranks}")
     args = ap.parse_args()
+    conf = CONFIG_DEFAULTS[args.config]
+    if args.frames is None:
+        args.frames = conf["frames"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:]))  # nothing has touched the GPU in this process
@@ -518,16 +629,55 @@ def main() -> None:
 
     dims = synth.VIT_B_16
     sd = synth.make_state_dict(dims, seed=42)
-    n_local, n_total = args.clips, args.clips * world
-    video = synth_video_on_device(n_local, args.frames, dims.image_resolution, seed=1000 + rank, device=device)
-    ids = torch.from_numpy(synth.make_text(n_local, dims, seed=42, first_text=rank * n_local)).to(device)
+    if args.config == "c2":
+        counts = [args.clips] * world
+        eval_batch = None
+    else:
+        total = args.total_clips or conf["total_clips"]
+        if total < world:
+            raise SystemExit(f"--config {args.config}: {total} clips cannot be sharded over {world} ranks")
+        counts = D.shard_counts(total, world)
+        eval_batch = args.eval_batch or conf.get("eval_batch")
+    shards = Shards(counts, rank, eval_batch)
+    n_local, n_total = shards.n_local, shards.n_total
+    sharding = (f"{n_total} clips in exact contiguous shards {counts if len(set(counts)) > 1 else f'of {counts[0]}'} over {world} "
+                f"rank(s)")
+    base = {"metric": "video-text pairs/sec (8-frame 224^2, 77-tok)", "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "higher_is_better": True, "scaling": conf["scaling"], "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic"}
+    collectives = f"{args.backend} process group, {world} rank(s)" if grouped else "none (single process)"
+
+    if args.config == "c5":
+        kd = run_kd_config(sd, dims, args, shards, device, args.backend)
+        result = {**base, "metric": "video-text pairs/sec through the KD training step (8-frame 224^2, 77-tok)",
+                  "value": kd["value"], "ms_per_step": kd["ms_per_step"],
+                  "config": {"workload": f"KD training step, teacher + student CLIP ViT-B/16 dual forward, {n_total} clips x "
+                                         f"{args.frames} frames x 224^2 + {n_total} x 77-token texts in total, half labeled on "
+                                         f"every rank -> NCE + KD losses -> student backward -> AdamW (BASELINE configs[4])",
+                             "total_clips": n_total, "frames": args.frames, "sharding": sharding,
+                             "exchange": "one packed all-gather of the four [n_local, 512] embedding matrices + three "
+                                         "all-reduces of the flat gradient buffer per step",
+                             "weights": "random init (seed 42) teacher, student = teacher perturbed by 5 %; AdamW lr 3e-7",
+                             "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
+                             "collectives": collectives},
+                  "roofline": kd["roofline"], "losses": kd["losses"], "peak_memory_gb": kd["peak_memory_gb"]}
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if grouped:
+            dist.destroy_process_group()
+        return
+
+    video = fill_video(n_local, args.frames, dims.image_resolution, seed=1000 + rank, device=device)
+    ids = torch.from_numpy(synth.make_text(n_local, dims, seed=42, first_text=shards.offset)).to(device)
     text = {"input_ids": ids}
 
     weights_note = "random init (seed 42)"
     unplanted = {k: sd[k].copy() for k in PLANTED}  # the training leg uses the plain random towers
     if not args.no_plant:
-        # one model for all ranks: rank 0 plants on its own clips, everybody receives the three tensors
-        planted = plant_retrieval_weights(sd, video, ids, dims, device, block=args.cpu_sample_clips) if rank == 0 else None
+        # one model for all ranks: rank 0 plants on (the first 256 of) its own clips, everybody receives the three tensors
+        k_plant = min(n_local, 256)
+        planted = plant_retrieval_weights(sd, video[:k_plant], ids[:k_plant], dims, device,
+                                          block=args.cpu_sample_clips) if rank == 0 else None
         if grouped:
             for k in PLANTED:
                 t = torch.from_numpy(planted[k]).to(device) if rank == 0 else torch.empty(sd[k].shape, device=device)
@@ -540,32 +690,40 @@ def main() -> None:
         weights_note += " + planted visual.proj / ln_post.bias / text_projection (retrieval task, see `retrieval`)"
         torch.cuda.empty_cache()
 
-    head, (ev, et, all_ranks) = run_mode(args.precision, sd, video, text, args, world, rank, device, args.backend, True)
+    head, (ev, et, all_ranks) = run_mode(args.precision, sd, video, text, args, shards, device, args.backend, True)
     metrics = D.metrics_from_ranks(all_ranks.cpu().numpy())
+    if args.config == "c2":
+        workload = (f"CLIP ViT-B/16 dual encoder, {n_local} clips x {args.frames} frames x 224^2 + {n_local} x 77-token texts per "
+                    f"GPU -> T@V^T -> ranks (BASELINE configs[1])")
+    else:
+        workload = (f"CLIP ViT-B/16 dual encoder, {n_total} clips x {args.frames} frames x 224^2 + {n_total} x 77-token texts in "
+                    f"total, sharded by clip, eval batches of {shards.eval_batch or n_local} clips -> one all-gather -> row-block "
+                    f"T@V^T -> ranks (BASELINE configs[3])")
     result = {
-        "metric": "video-text pairs/sec (8-frame 224^2, 77-tok)", "value": head["value"],
-        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"CLIP ViT-B/16 dual encoder, {n_local} clips x {args.frames} frames x 224^2 + {n_local} "
-                               f"x 77-token texts per GPU -> T@V^T -> ranks (BASELINE configs[1])",
-                   "clips_per_gpu": n_local, "frames": args.frames, "weights": weights_note,
+        **base, "value": head["value"], "ms_per_step": head["ms_per_step"],
+        "instrumented_repeat_ms_per_step": head["instrumented_repeat_ms_per_step"], "dtype": args.precision,
+        "config": {"workload": workload, "clips_per_gpu": n_local if len(set(counts)) == 1 else counts, "frames": args.frames,
+                   "weights": weights_note,
                    "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate" if args.precision == "fp32"
                                  else "bf16 MFMA operands, fp32 accumulate / residual / LayerNorm / softmax statistics",
                    "prune_last_block": bool(args.prune_last_block),
-                   "sharding": f"clips over {world} rank(s), one RCCL all-gather of embeddings",
-                   "collectives": f"{args.backend} process group, {world} rank(s)" if grouped else "none (single process)"},
+                   "sharding": f"{sharding}, one RCCL all-gather of embeddings",
+                   "collectives": collectives},
         "roofline": head["roofline"], "roofline_all_gemms": head["roofline_all_gemms"],
         "roofline_whole_path": head["roofline_whole_path"], "roofline_vit_forward": head["roofline_vit_forward"],
         "time_split": head["time_split"],
         "retrieval": {**metrics, "n": n_total, "path": f"device, {args.precision}"},
     }
+    legs = Legs(result, world)
+    secondary = args.config == "c2" and args.precision == "fp32" and (world == 1 or args.all_legs)
+    if not secondary and world > 1:
+        result["secondary_legs"] = "skipped with more than one rank (headline leg only); --all-legs runs them"
 
     ev16 = et16 = None
 
     def bf16_leg():
         torch.cuda.empty_cache()
-        b16, (v16, t16, ranks16) = run_mode("bf16", sd, video, text, args, world, rank, device, args.backend, False)
+        b16, (v16, t16, ranks16) = run_mode("bf16", sd, video, text, args, shards, device, args.backend, False)
         m16 = D.metrics_from_ranks(ranks16.cpu().numpy())
         b16["retrieval"] = m16
         b16["recall_delta_vs_fp32_path"] = {k: round(m16[k] - metrics[k], 6) for k in ("r1", "r5", "r10", "mr")}
@@ -575,8 +733,8 @@ def main() -> None:
         result["bf16_mode"] = b16
         return v16, t16
 
-    if not args.no_bf16_mode and args.precision == "fp32":
-        got = guarded(result, "bf16_mode", world, bf16_leg)
+    if secondary and not args.no_bf16_mode:
+        got = legs.run("bf16_mode", bf16_leg)
         if got is not None:
             ev16, et16 = got
 
@@ -584,7 +742,7 @@ def main() -> None:
 
     def split_leg():
         torch.cuda.empty_cache()
-        s6, (v6, t6, ranks6) = run_split_mode(sd, video, text, args, world, rank, device, args.backend)
+        s6, (v6, t6, ranks6) = run_split_mode(sd, video, text, args, shards, device, args.backend)
         m6 = D.metrics_from_ranks(ranks6.cpu().numpy())
         s6["retrieval"] = m6
         s6["recall_delta_vs_fp32_path"] = {k: round(m6[k] - metrics[k], 6) for k in ("r1", "r5", "r10", "mr")}
@@ -596,13 +754,13 @@ def main() -> None:
         result["fp32_split_mode"] = s6
         return v6, t6
 
-    if not args.no_split_mode and args.precision == "fp32":
-        got = guarded(result, "fp32_split_mode", world, split_leg)
+    if secondary and not args.no_split_mode:
+        got = legs.run("fp32_split_mode", split_leg)
         if got is not None:
             ev6, et6 = got
 
-    if rank == 0 and world == 1 and not args.no_train_leg and n_local >= 4:
-        got = guarded(result, "kd_training_step", world, lambda: training_leg({**sd, **unplanted}, video, ids, args, dims, device))
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_train_leg and n_local >= 4:
+        got = legs.run("kd_training_step", lambda: training_leg({**sd, **unplanted}, video, ids, args, dims, device))
         if got is not None:
             result["kd_training_step"] = got
 
@@ -672,11 +830,15 @@ def main() -> None:
         return True
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        guarded(result, "cpu_baseline", world, cpu_leg)
+        legs.run("cpu_baseline", cpu_leg)  # needs the device only to compare the embeddings it already holds
+    if legs.failed:
+        result["failed_legs"] = legs.failed
     if rank == 0:
         print(json.dumps(result), flush=True)
     if grouped:
         dist.destroy_process_group()
+    if legs.failed:
+        raise SystemExit(1)  # the headline line above is complete; the exit code says a secondary leg is broken
 
 
 if __name__ == "__main__":

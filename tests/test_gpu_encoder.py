@@ -608,3 +608,55 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert line["n_gpus"] == 2 and line["dtype"] == "fp32" and line["scaling"] == "weak"
     assert line["retrieval"]["n"] == 32 and line["value"] > 0
     assert line["retrieval"]["r1"] > 0.2  # rank 0's captions are planted on their clips; chance would be 1/32
+
+
+def test_bench_config_c4_strong_scaling_rehearsal_with_a_ragged_shard():
+    """`bench.py --config c4` (BASELINE configs[3], shrunk): a FIXED total of clips in exact contiguous shards - 21 clips over two
+    ranks = 11 + 10 - encoded in eval batches of 4, one all-gather, row-block scoring; the retrieval metrics over all 21 clips
+    equal the one-rank run of the same command (same inputs per global clip index is not required: metrics are per run)."""
+    common = ["bench.py", "--config", "c4", "--total-clips", "21", "--frames", "2", "--eval-batch", "4", "--steps", "1",
+              "--warmup", "1", "--no-cpu-baseline", "--no-plant"]
+    two = _run(common + ["--gpus", "2", "--backend", "gloo"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["retrieval"]["n"] == 21 and two["value"] > 0
+    assert two["config"]["clips_per_gpu"] == [11, 10] and "configs[3]" in two["config"]["workload"]
+    assert "bf16_mode" not in two and "fp32_split_mode" not in two and "skipped" in two["secondary_legs"]
+    one = _run(common)
+    assert one["n_gpus"] == 1 and one["retrieval"]["n"] == 21 and one["config"]["clips_per_gpu"] == 21
+    assert one["roofline"]["frac"] > 0 and one["instrumented_repeat_ms_per_step"] > 0
+
+
+def test_bench_config_c5_kd_training_step_rehearsal():
+    """`bench.py --config c5` (BASELINE configs[4], shrunk): the teacher + student KD training step on 12 clips in total; on two
+    gloo ranks (6 + 6, half labeled on each) the step exchanges the packed embeddings and the three gradient slices; the first
+    loss equals the one-rank run's up to the summation order of the gathered batch."""
+    common = ["bench.py", "--config", "c5", "--total-clips", "12", "--frames", "2", "--steps", "2", "--warmup", "1"]
+    two = _run(common + ["--gpus", "2", "--backend", "gloo"])
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["value"] > 0 and "configs[4]" in two["config"]["workload"]
+    assert len(two["losses"]) == 3 and all(np.isfinite(two["losses"]))
+    assert two["roofline"]["frac"] > 0 and two["roofline"]["bound"] == "mfma"
+    one = _run(common)
+    assert one["n_gpus"] == 1 and len(one["losses"]) == 3 and all(np.isfinite(one["losses"]))
+
+
+def test_bench_exits_nonzero_when_a_secondary_leg_fails():
+    """A broken secondary leg must not hide behind rc 0: the headline line is still printed (with `failed_legs`), the exit
+    code is 1.  The failure is injected from outside (an impossible tile for the bf16 leg only is not available, so the
+    oracle import of the CPU leg is broken through PYTHONPATH shadowing)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = __import__("pathlib").Path(__file__).resolve().parent.parent
+    with tempfile.TemporaryDirectory() as tmp:
+        shadow = os.path.join(tmp, "sitecustomize.py")
+        with open(shadow, "w") as f:  # makes `from oracle import clip_oracle` raise inside bench.py's cpu_baseline leg
+            f.write("import sys, types\nm = types.ModuleType('oracle')\nm.__path__ = []\nsys.modules['oracle'] = m\n")
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env["PYTHONPATH"] = tmp + os.pathsep + env.get("PYTHONPATH", "")
+        res = subprocess.run([sys.executable, "bench.py", "--clips", "8", "--frames", "1", "--steps", "1", "--warmup", "1",
+                              "--no-bf16-mode", "--no-split-mode", "--no-train-leg", "--cpu-sample-clips", "4"],
+                             capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert res.returncode == 1, (res.returncode, res.stderr[-2000:])
+    import json
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] > 0 and line["failed_legs"] == ["cpu_baseline"] and "error" in line["cpu_baseline"]
