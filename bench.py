@@ -409,8 +409,8 @@ def run_mode(precision, sd, video, text, args, shards, device, backend, full_det
 
 def run_split_mode(sd, video, text, args, shards, device, backend):
     """Secondary leg `fp32_split_mode` (precision "fp32x6"): the same step with the visual tower's block GEMMs on the bf16
-    matrix cores over split-fp32 operands (three bf16 numbers per value, six bf16 products per fp32 product, fp32
-    accumulate) - fp32 accuracy from the pipe that is 16x faster than the fp32-input one.  Timed like the headline; the
+    matrix cores over split-fp32 operands (three bf16 planes per value, six bf16 products per fp32 product formed from
+    registers, fp32 accumulate: csrc/gemm_split3.h) - fp32 accuracy from the pipe that is 16x faster than the fp32-input one.  Timed like the headline; the
     per-kernel figures come from one instrumented extra step."""
     from fitclip_amd.clip_model import build_clip
     from fitclip_amd.encoder import ClipVideoTextEncoder
@@ -438,7 +438,7 @@ def run_split_mode(sd, video, text, args, shards, device, backend):
         by[(r["epilogue"], r["N"], r["K"], r["M"])][1] += 1
     (epi, N, K6, M), (ms, cnt) = max(by.items(), key=lambda kv: kv[1][0])
     bf16_flops = 2.0 * M * N * K6  # executed on the bf16 pipe: six products per fp32 product
-    epi_name = {6: "bias_f32_out", 7: "bias_quickgelu_six_plane_out"}[epi]
+    epi_name = {6: "bias_f32_out", 7: "bias_quickgelu_x3_out"}[epi]
     traffic, traffic_note = load_traffic("fp32x6", (M, N, K6), epi_name)
     six_ms = sum(r["ms"] for r in six)
     six_flops = sum(2.0 * r["M"] * r["N"] * r["K"] for r in six)
@@ -448,8 +448,8 @@ def run_split_mode(sd, video, text, args, shards, device, backend):
         "value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate; LayerNorm, "
                  "softmax, residual stream, patch embedding and the text tower in plain fp32",
-        "roofline": {"bound": "mfma", "kernel": f"gemm_pipelined_kernel<256x256><bf16 six-plane operands,"
-                                                f"{epi_name}> M={M} N={N} K={K6} (= 6 x {K6 // 6})",
+        "roofline": {"bound": "mfma", "kernel": f"gemm_split3_kernel<256x256><three bf16 planes per operand, six MFMA products "
+                                                f"per fp32 product, {epi_name}> M={M} N={N} K={K6 // 6} (x 6 products)",
                      "achieved": round(bf16_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                      "frac": round(bf16_flops * cnt / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),
                      "fp32_equivalent_tflops": round(bf16_flops / 6 * cnt / (ms * 1e-3) / 1e12, 1),

@@ -15,7 +15,7 @@ _CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("FITCLIP_HIP_LIB", _CSRC / "libfitclip_hip.so"))
 
 PREC_F32, PREC_BF16 = 0, 1
-EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_DGELU_T, EPI_BIAS_F32, EPI_GELU_X6 = range(8)
+EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_DGELU_T, EPI_BIAS_F32, EPI_GELU_X3 = range(8)
 
 
 class FitclipHipError(RuntimeError):
@@ -74,7 +74,8 @@ SIGNATURES = {
     "fc_add_layernorm": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fc_attention": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "fc_convert": (_i32, [_vp, _vp, _i32, _sz, _vp]),
-    "fc_split6": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "fc_split3": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "fc_gemm_split3": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fc_set_grad": (_i32, [_vp, C.c_char_p, _vp]),
     "fc_train_weights_bytes": (_sz, [_vp]),
     "fc_train_prepare": (_i32, [_vp, _vp, _sz, _vp]),

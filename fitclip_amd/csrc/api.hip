@@ -99,7 +99,7 @@ size_t numel(const std::vector<int64_t>& s) {
 }
 
 // GEMM weights that get a kernel-layout copy
-enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS, PACK_SPLIT6 };
+enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS, PACK_SPLIT3 };
 struct PackItem {
   std::string name;
   PackMode mode;
@@ -122,11 +122,11 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
     blocks("visual.transformer", h->cfg.vision_layers);
     blocks("transformer", h->cfg.transformer_layers);
   }
-  if (h->split()) {  // six-plane bf16 images of the visual tower's block weights (the fp32 tensors stay in use as well)
+  if (h->split()) {  // x3 rows (three bf16 planes) of the visual tower's block weights (the fp32 tensors stay in use as well)
     for (int i = 0; i < h->cfg.vision_layers; ++i) {
       const std::string b = "visual.transformer.resblocks." + std::to_string(i);
       for (const char* n : {".attn.in_proj_weight", ".attn.out_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight"})
-        l.push_back({b + n, PACK_SPLIT6});
+        l.push_back({b + n, PACK_SPLIT3});
     }
   }
   l.push_back({"visual.proj", PACK_TRANSPOSE});
@@ -135,7 +135,7 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
 }
 size_t packed_item_bytes(const fc_handle* h, const PackItem& e) {
   const auto& shape = h->slots.at(e.name).shape;
-  if (e.mode == PACK_SPLIT6) return align_up(numel(shape) * X6_PLANES * 2);
+  if (e.mode == PACK_SPLIT3) return align_up((size_t)shape[0] * (size_t)x3_row_elems(shape[1]) * 2);
   const size_t n = e.mode == PACK_PAD_ROWS ? (size_t)shape[0] * h->patch_kp() : numel(shape);
   return align_up(n * h->esz);
 }
@@ -194,14 +194,14 @@ struct Scratch {
 };
 
 // workspace carve for `c` items of `tokens` tokens and width `w` (base may be null: sizes only).  `split`: the layout
-// of the split-fp32 visual tower - xn holds six-plane rows (12 w bytes), big the fp32 QKV rows or the six-plane MLP
-// hidden rows (48 w bytes), d the fp32 deltas; it contains the plain fp32 layout, which small passes fall back to.
+// of the split-fp32 visual tower - xn holds x3 rows (8 w bytes of address space), big the fp32 QKV rows or the x3 MLP
+// hidden rows (32 w bytes), d the fp32 deltas; it contains the plain fp32 layout, which small passes fall back to.
 Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, bool split = false) {
   Scratch s{};
   const size_t M = (size_t)c * tokens;
   const size_t big_cols = (size_t)std::max(4 * w, min_big_cols);
-  const size_t xn_row = split ? (size_t)w * X6_PLANES * 2 : (size_t)w * esz;
-  const size_t big_row = split ? std::max(big_cols * esz, (size_t)4 * w * X6_PLANES * 2) : big_cols * esz;
+  const size_t xn_row = split ? (size_t)x3_row_elems(w) * 2 : (size_t)w * esz;
+  const size_t big_row = split ? std::max(big_cols * esz, (size_t)x3_row_elems(4 * w) * 2) : big_cols * esz;
   const size_t o_x = 0;
   const size_t o_xn = o_x + align_up(M * w * 4);
   const size_t o_big = o_xn + align_up(M * xn_row);
@@ -284,59 +284,57 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
 }
 
 // ---- split-fp32 visual tower (cfg.split_gemm): the same block sequence with the four big GEMMs on the bf16 matrix
-// cores over six-plane operands (common.h).  Producers write the six-plane image directly: LayerNorm (KIND_X6), the
-// fp32 attention kernel, c_fc's QuickGELU epilogue (EPI_GELU_X6); QKV / out_proj / c_proj return fp32 (EPI_BIAS_F32).
+// cores over three-plane operands (gemm_split3.h, common.h).  Producers write x3 rows directly: LayerNorm (KIND_X3), the
+// fp32 attention kernel, c_fc's QuickGELU epilogue (EPI_GELU_X3); QKV / out_proj / c_proj return fp32 (EPI_BIAS_F32).
 // Everything else - residual stream, LayerNorm statistics, softmax - is the fp32 path's code.
-int gemm_x6(fc_handle* h, int epi, const void* A6, const void* W6, const float* bias, void* C, int M, int N, int K,
+int gemm_x3(fc_handle* h, int epi, const void* A3, const void* W3, const float* bias, void* C, int M, int N, int K,
             int ldc, hipStream_t st) {
   GemmArgs a{};
-  a.A = A6; a.W = W6; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
-  a.M = M; a.N = N; a.K = X6_PLANES * K; a.lda = a.K; a.ldw = a.K; a.ldc = ldc; a.P = 0;
-  // c_fc (12 column tiles): four XCD groups split the N range, so that only a quarter of the 28 MB six-plane weight
-  // competes for each L2 (2.72 -> 2.57 ms at 512 frames; no effect on the shapes with 3 or 9 column tiles)
-  if ((N / 256) % 4 == 0 && N / 256 >= 8 && N % 256 == 0) a.nsplit = 4;
-  ProfScope ps(h, st, PREC_BF16, epi, 3, a);
-  return launch_gemm(PREC_BF16, epi, a, 0, st);
+  a.A = A3; a.W = W3; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
+  a.M = M; a.N = N; a.K = K; a.lda = (int)x3_row_elems(K); a.ldw = a.lda; a.ldc = ldc; a.P = 0;
+  GemmArgs rec = a;  // the profiling record counts the bf16 work: six products per fp32 product
+  rec.K = 6 * K;
+  ProfScope ps(h, st, PREC_BF16, epi, 3, rec);
+  return launch_gemm_split3(epi, a, st);
 }
 
-// The six-plane GEMMs only exist on the pipelined kernel: a pass qualifies when its widest operand - the six-plane MLP
-// hidden rows, 48 w bytes each - stays below the 4 GiB of the kernel's 32-bit operand offsets, and K = 6 w spans the
-// three K-tiles its prologue assumes.
-bool x6_pass_ok(int M, int w) {
-  return M > 0 && (size_t)M * 4 * w * X6_PLANES * 2 < (1ull << 32) && X6_PLANES * w >= 3 * 64;  // K-tile of the bf16 kernel: 64 columns
+// A pass qualifies for the three-plane GEMMs when its widest operand - the x3 MLP hidden rows, 32 w bytes each - stays
+// below the 4 GiB of the kernel's 32-bit row offsets and K spans the K-steps its prologue assumes.
+bool x3_pass_ok(int M, int w) {
+  return M > 0 && (size_t)M * (size_t)x3_row_elems(4 * w) * 2 < (1ull << 32) && w >= 64 && w % 32 == 0;
 }
 
-int run_blocks_x6(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,
+int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,
                   const float* fin_b, long pool_step, hipStream_t st, const TowerEntry& entry) {
   const int M = n_seq * S;
-  const long ld6 = (long)X6_PLANES * w;
+  const long ld3 = x3_row_elems(w);
   const size_t nl = t.blocks.size();
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
     if (l == 0) {
       FC_TRY(launch_layernorm_pair(s.x, entry.cls, entry.pos0, S, entry.pre_w, entry.pre_b, b.ln1_w, b.ln1_b, s.xn,
-                                   KIND_X6, M, w, st));
+                                   KIND_X3, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld6, KIND_X6, M, w, 1, 0, st));
+      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
     }
-    FC_TRY(gemm_x6(h, EPI_BIAS_F32, s.xn, b.in_w6, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
+    FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.in_w3, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
-      if (attention_x6_supported(S, 0)) {
-        FC_TRY(launch_attention_x6(s.big, s.xn, n_seq, S, heads, st));
+      if (attention_x3_supported(S, 0)) {
+        FC_TRY(launch_attention_x3(s.big, s.xn, n_seq, S, heads, st));
       } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
         FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
-        FC_TRY(launch_split6(s.d, w, s.xn, ld6, M, w, 0, st));
+        FC_TRY(launch_split3_rows(s.d, w, s.xn, ld3, M, w, st));
       }
     }
-    FC_TRY(gemm_x6(h, EPI_BIAS_F32, s.xn, b.out_w6, b.out_b, s.d, M, w, w, w, st));
+    FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.out_w3, b.out_b, s.d, M, w, w, w, st));
     {
       ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld6, KIND_X6, M, w, 1, 0, st));
+      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
     }
-    FC_TRY(gemm_x6(h, EPI_GELU_X6, s.xn, b.fc_w6, b.fc_b, s.big, M, 4 * w, w, X6_PLANES * 4 * w, st));
-    FC_TRY(gemm_x6(h, EPI_BIAS_F32, s.big, b.proj_w6, b.proj_b, s.d, M, w, 4 * w, w, st));
+    FC_TRY(gemm_x3(h, EPI_GELU_X3, s.xn, b.fc_w3, b.fc_b, s.big, M, 4 * w, w, (int)x3_row_elems(4 * w), st));
+    FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.big, b.proj_w3, b.proj_b, s.d, M, w, 4 * w, w, st));
   }
   // the last c_proj delta is still pending in s.d: fold it into the final LayerNorm of the pooled rows
   const long xs_pool = pool_step * w;
@@ -368,10 +366,10 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
   if (c.precision != FC_PREC_F32) return 512;
-  if (h->split()) {  // bf16-pipe GEMMs: no whole-round planning (as in bf16 mode); the six-plane MLP rows of a pass (48 w
-    // bytes each) must stay below the 4 GiB of the kernel's 32-bit operand offsets
-    const long max6 = (long)(((1LL << 32) - 1) / (8LL * c.vision_width * X6_PLANES) / h->vtokens());
-    return (int)std::max(1L, std::min(512L, max6));
+  if (h->split()) {  // bf16-pipe GEMMs: no whole-round planning (as in bf16 mode); the x3 MLP rows of a pass (32 w bytes each)
+    // must stay below the 4 GiB of the kernel's 32-bit row offsets
+    const long max3 = (long)(((1LL << 32) - 1) / (2LL * x3_row_elems(4L * c.vision_width)) / h->vtokens());
+    return (int)std::max(1L, std::min(512L, max3));
   }
   const long T = h->vtokens(), w = c.vision_width, cus = device_cus();
   const long max_frames = std::max(1L, (long)((1LL << 32) - 1) / (16 * w) / T);  // 32-bit operand offsets of the 4w-wide buffer
@@ -493,10 +491,10 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       FC_TRY(launch_transpose_convert(slot.ptr, dst, kind, (int)slot.shape[0], (int)slot.shape[1], stream));
     } else if (e.mode == PACK_PAD_ROWS) {
       FC_TRY(launch_convert_rows(slot.ptr, dst, kind, (long)slot.shape[0], h->patch_k(), h->patch_kp(), stream));
-    } else if (e.mode == PACK_SPLIT6) {
-      FC_TRY(launch_split6(slot.ptr, (long)slot.shape[1], dst, (long)slot.shape[1] * X6_PLANES, (long)slot.shape[0],
-                           (int)slot.shape[1], 1, stream));
-      packed[e.name + "#x6"] = dst;
+    } else if (e.mode == PACK_SPLIT3) {
+      FC_TRY(launch_split3_rows(slot.ptr, (long)slot.shape[1], dst, x3_row_elems(slot.shape[1]), (long)slot.shape[0],
+                                (int)slot.shape[1], stream));
+      packed[e.name + "#x3"] = dst;
       off += packed_item_bytes(h, e);
       continue;
     } else {
@@ -520,12 +518,12 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       k.fc_b = h->w(b + ".mlp.c_fc.bias"); k.proj_b = h->w(b + ".mlp.c_proj.bias");
       k.in_w = gw(b + ".attn.in_proj_weight"); k.out_w = gw(b + ".attn.out_proj.weight");
       k.fc_w = gw(b + ".mlp.c_fc.weight"); k.proj_w = gw(b + ".mlp.c_proj.weight");
-      auto x6 = [&](const char* n) -> const void* {
-        auto it = packed.find(b + n + "#x6");
+      auto x3 = [&](const char* n) -> const void* {
+        auto it = packed.find(b + n + "#x3");
         return it != packed.end() ? it->second : nullptr;
       };
-      k.in_w6 = x6(".attn.in_proj_weight"); k.out_w6 = x6(".attn.out_proj.weight");
-      k.fc_w6 = x6(".mlp.c_fc.weight"); k.proj_w6 = x6(".mlp.c_proj.weight");
+      k.in_w3 = x3(".attn.in_proj_weight"); k.out_w3 = x3(".attn.out_proj.weight");
+      k.fc_w3 = x3(".mlp.c_fc.weight"); k.proj_w3 = x3(".mlp.c_proj.weight");
     }
   };
   fill(h->vis, "visual.transformer", h->cfg.vision_layers);
@@ -584,8 +582,8 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     }
     const TowerEntry entry{h->w("visual.class_embedding"), h->w("visual.positional_embedding"),
                            h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias")};
-    if (split && x6_pass_ok(cn * T, vw)) {
-      FC_TRY(run_blocks_x6(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
+    if (split && x3_pass_ok(cn * T, vw)) {
+      FC_TRY(run_blocks_x3(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
                            h->w("visual.ln_post.bias"), T, st, entry));
     } else {  // (split mode: a pass too small for the pipelined GEMM takes the plain fp32 path)
       FC_TRY(run_blocks(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),
@@ -687,19 +685,26 @@ int fc_add_layernorm(float* x, int64_t xs, const void* delta, int64_t ds, const 
 }
 int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream st) {
-  if (precision == KIND_X6) {  // fp32 in, six-plane bf16 out (the sequence lengths the streaming-block kernel serves)
-    if (causal) return fail(FC_EINVAL, "fc_attention: the six-plane output is not available for causal attention");
-    return launch_attention_x6(qkv, out, n_seq, S, heads, st);
+  if (precision == KIND_X3) {  // fp32 in, x3 rows out (the sequence lengths the streaming-block kernel serves)
+    if (causal) return fail(FC_EINVAL, "fc_attention: the three-plane output is not available for causal attention");
+    return launch_attention_x3(qkv, out, n_seq, S, heads, st);
   }
   return launch_attention(precision, qkv, out, n_seq, S, heads, causal, st);
 }
 int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream st) {
   return launch_convert(in, out, out_kind, n, st);
 }
-int fc_split6(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t is_weight,
-              fc_stream st) {
-  if (!in || !out) return fail(FC_EINVAL, "fc_split6: null operand");
-  return launch_split6(in, (long)ld_in, out, (long)ld_out, (long)rows, K, is_weight, st);
+int fc_split3(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, fc_stream st) {
+  if (!in || !out) return fail(FC_EINVAL, "fc_split3: null operand");
+  return launch_split3_rows(in, (long)ld_in, out, (long)ld_out, (long)rows, K, st);
+}
+int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, const float* bias, void* C, int32_t M, int32_t N,
+                   int32_t K, int32_t lda, int32_t ldw, int32_t ldc, fc_stream st) {
+  GemmArgs a{};
+  a.A = A3; a.W = W3; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc;
+  if (!A3 || !W3 || !C) return fail(FC_EINVAL, "fc_gemm_split3: null operand");
+  return launch_gemm_split3(epilogue, a, st);
 }
 
 int fc_profile_enable(fc_handle* h, int32_t max_records) {

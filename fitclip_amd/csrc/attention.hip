@@ -667,8 +667,8 @@ __device__ __forceinline__ float exp_neg_finite_f32(float x) {
   const float e = __builtin_amdgcn_exp2f(t);
   return __builtin_fmaf(e, r * 0.6931471805599453f, e);
 }
-// X6: `out` is the six-plane bf16 image [rows, 6 D] of the fp32 result (split-fp32 mode: out_proj's A operand).
-template <int NW, int ABL = 0, bool X6 = false>
+// X3: `out` is written as x3 rows [rows, 4 D bf16 positions] of the fp32 result (split-fp32 mode: out_proj's A operand).
+template <int NW, int ABL = 0, bool X3 = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4)))  // <= 128 VGPRs: two workgroups per CU
 attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads) {
   constexpr int BT = 4, BK = BT * 16;          // key tiles / keys per block
@@ -805,13 +805,15 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
       }
     }
   }
-  if constexpr (X6) {
-    // Six-plane rows: the 64 columns of a head are two 32-column groups = 2 x 384 contiguous bytes per query row.  Each
-    // wave stages the three planes of a 16-row x 32-column patch in its own 3 KiB of the (now idle) K/V buffers
-    // (16-byte chunk ^ (row >> 2) & 3) and writes them out as whole rows: 64 lanes x 16 bytes = 2.67 rows per store.
+  if constexpr (X3) {
+    // x3 rows (common.h): the 64 columns of a head are four 128-byte lines [p1 | p2 | p3 | unused] per query row.  Each wave
+    // stages the planes of a 16-row x 32-column patch (two lines per row: 16 x 192 bytes, rows 208 bytes apart against
+    // bank conflicts) in its own 4 KiB of the (now idle) K/V buffers and writes them out as WHOLE lines, 16 bytes per lane:
+    // chunk x = 16 row + 8 line + c lands at byte 16 c of that line (c = 6, 7: zeros - a partly written line costs a
+    // read-modify-write at the memory side).
     __syncthreads();  // every wave is done reading K / V
     char* stg = smem + wave * 4096;
-    const int sub = lane & 3;
+    constexpr int ROWS = 208;
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
       const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
@@ -823,24 +825,21 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
         for (int nh = 0; nh < 2; ++nh) {
           bf16x4 p1, p2, p3;
           split3(o[qi][2 * gs + nh] * inv, p1, p2, p3);
-          const int off = r * 64 + (((nh * 2 + (g >> 1)) ^ ((r >> 2) & 3)) << 4) + ((g & 1) << 3);
-          *reinterpret_cast<bf16x4*>(stg + off) = p1;
-          *reinterpret_cast<bf16x4*>(stg + 1024 + off) = p2;
-          *reinterpret_cast<bf16x4*>(stg + 2048 + off) = p3;
+          char* w0 = stg + r * ROWS + nh * 96 + g * 8;  // lane (r, g): columns 4 g .. 4 g + 3 of 16-column block 2 gs + nh
+          *reinterpret_cast<bf16x4*>(w0) = p1;
+          *reinterpret_cast<bf16x4*>(w0 + 32) = p2;
+          *reinterpret_cast<bf16x4*>(w0 + 64) = p3;
         }
-        bf16* obase = reinterpret_cast<bf16*>(out) + ((long)seq * S + q0) * (X6_PLANES * D) +
-                      (h * 2 + gs) * (X6_CHUNK * X6_PLANES);
+        char* obase = reinterpret_cast<char*>(out) + ((long)seq * S + q0) * ((long)D * 8) + (long)(h * 4 + gs * 2) * X3_GROUP_BYTES;
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-          const int idx = it * 64 + lane, row = idx / 24, ch = idx - row * 24;  // 24 chunks of 16 bytes per row
-          const int slot = ch >> 2;                                             // planes [p1 p1 p2 p2 p1 p3]
-          const int plane = slot == 5 ? 2 : (slot == 2 || slot == 3) ? 1 : 0;
-          const bf16x8 val = *reinterpret_cast<const bf16x8*>(stg + plane * 1024 + row * 64 + (((ch & 3) ^ ((row >> 2) & 3)) << 4));
-          if (q0 + row < S) *reinterpret_cast<bf16x8*>(obase + (long)row * (X6_PLANES * D) + ch * 8) = val;
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 64 + lane, row = idx >> 4, line = (idx >> 3) & 1, c = idx & 7;  // 16 chunks of 16 bytes per row
+          bf16x8 val = {};
+          if (c < 6) val = *reinterpret_cast<const bf16x8*>(stg + row * ROWS + (line * 6 + c) * 16);
+          if (q0 + row < S) *reinterpret_cast<bf16x8*>(obase + (long)row * ((long)D * 8) + line * X3_GROUP_BYTES + c * 16) = val;
         }
       }
     }
-    (void)sub;
   } else {
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
@@ -988,9 +987,9 @@ int launch_f32_mfma(const void* qkv, void* out, int n_seq, int S, int heads, hip
   return FC_OK;
 }
 
-int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st, bool x6 = false) {
+int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t st, bool x3 = false) {
   constexpr int NW = 8, lds = 2 * (64 * 256 + 16 * (1024 + 64));  // two 33 KiB buffers (64 keys of K and V): two workgroups per CU
-  if (x6)
+  if (x3)
     hipLaunchKernelGGL((attn_f32_blocks_kernel<NW, 0, true>), dim3(n_seq * heads), dim3(NW * 64), lds, st,
                        (const float*)qkv, (float*)out, S, heads);
   else
@@ -1015,14 +1014,14 @@ int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int cau
 
 }  // namespace
 
-// fp32 attention whose output is the six-plane bf16 image [n_seq * S, 6 * heads * 64] (split-fp32 mode).  Only the
-// streaming-block kernel writes it directly (the ViT's 197 tokens); `attention_x6_supported` tells the caller when to
-// run the plain fp32 kernel + fc_split6 instead.
-bool attention_x6_supported(int S, int causal) { return !causal && S > 112 && S <= 224; }
-int launch_attention_x6(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream) {
+// fp32 attention whose output is written as x3 rows [n_seq * S, 4 * heads * 64 bf16 positions] (split-fp32 mode).  Only the
+// streaming-block kernel writes them directly (the ViT's 197 tokens); `attention_x3_supported` tells the caller when to
+// run the plain fp32 kernel + launch_split3_rows instead.
+bool attention_x3_supported(int S, int causal) { return !causal && S > 112 && S <= 224; }
+int launch_attention_x3(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream) {
   if (n_seq <= 0) return FC_OK;
-  if (!attention_x6_supported(S, 0) || heads <= 0) return fail(FC_EINVAL, "attention(x6): S=%d heads=%d", S, heads);
-  if (((uintptr_t)qkv | (uintptr_t)out) & 15) return fail(FC_EINVAL, "attention(x6): unaligned operand");
+  if (!attention_x3_supported(S, 0) || heads <= 0) return fail(FC_EINVAL, "attention(x3): S=%d heads=%d", S, heads);
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 127)) return fail(FC_EINVAL, "attention(x3): unaligned operand");
   return launch_f32_blocks(qkv, out, n_seq, S, heads, stream, true);
 }
 

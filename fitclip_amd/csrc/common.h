@@ -42,18 +42,22 @@ enum Epilogue : int {
   EPI_PATCH_F32 = 3,  // C(f32)[m + m/P + 1] = acc + pos[(m % P) + 1]   (patch embedding into the token stream)
   EPI_STORE_F32 = 4,  // C(f32) = alpha * acc (+ bias if given)
   EPI_DGELU_T = 5,    // C(T)   = acc * quickgelu'(aux(T)[m, n])   (backward of c_fc's activation; aux laid out as C)
-  EPI_BIAS_F32 = 6,   // C(f32) = acc + bias                        (bf16 six-plane operands in, fp32 out: split-fp32 mode)
-  EPI_GELU_X6 = 7,    // C(bf16 [M, 6 N]) = six_planes(quickgelu(acc + bias))   (next GEMM's six-plane A operand)
+  EPI_BIAS_F32 = 6,   // gemm_split3 only: C(f32) = acc + bias                  (three-plane operands in, fp32 out)
+  EPI_GELU_X3 = 7,    // gemm_split3 only: C(x3 rows [M, 4 N bf16]) = three_planes(quickgelu(acc + bias))   (the next GEMM's A operand)
 };
 
-// ---- split-fp32 ("x6") operands.  An fp32 number is exactly the sum of three bf16 numbers, x = p1 + p2 + p3
-// (p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2), round to nearest), and a product x * y is recovered to 2^-26
-// from six bf16 products p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1.  Laid out along K - every 32 columns of an activation
-// row become the 192 bf16 [p1 p1 p2 p2 p1 p3] (32 each), of a weight row [q1 q2 q1 q2 q3 q1] - the sum of the six
-// products of every column is an ordinary bf16 dot product over 6 K columns, accumulated in fp32 by the bf16 MFMA GEMM.
-constexpr int KIND_X6 = 2;     // element-kind argument of the row kernels: output = six-plane bf16 rows (0 = f32, 1 = bf16)
-constexpr int X6_CHUNK = 32;   // columns per group
-constexpr int X6_PLANES = 6;   // bf16 copies per column
+// ---- split-fp32 operands.  An fp32 number is exactly the sum of three bf16 numbers, x = p1 + p2 + p3 (p1 = bf16(x),
+// p2 = bf16(x - p1), p3 = bf16(x - p1 - p2), round to nearest), and a product x * y is recovered to 2^-26 from six bf16
+// products p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1, each exact in the bf16 MFMA's fp32 accumulator.
+// Three-plane ("x3") rows, the operand format of gemm_split3.h: every plane is stored ONCE.  Every 16 columns of a row are
+// one 128-byte line [p1 x16 | p2 x16 | p3 x16 | 32 bytes never read or written]; the six products are formed from
+// registers by the kernel.  A row of K columns is K / 16 lines = 4 K bf16 positions (6 K bytes carry data).  (Round 2 laid
+// the six products out along K - [p1 p1 p2 p2 p1 p3] x [q1 q2 q1 q2 q3 q1], 12 bytes per value - for the unmodified bf16
+// dot-product kernel.)
+constexpr int KIND_X3 = 3;             // element-kind argument of the row kernels: output = x3 rows
+constexpr int X3_GROUP = 16;           // columns per line
+constexpr int X3_GROUP_BYTES = 128;    // bytes per line
+constexpr long x3_row_elems(long K) { return K / X3_GROUP * (X3_GROUP_BYTES / 2); }  // bf16 positions per row = 4 K
 #ifdef __HIPCC__
 // x = p1 + p2 + p3 exactly.  Contraction is switched off: hipcc would otherwise fuse `x - p1` with the multiply that
 // produced x (fma on the UNROUNDED product), and the planes would describe a number that is not the fp32 value x.
@@ -88,6 +92,12 @@ struct GemmArgs {
 
 // tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)
 int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStream_t stream);
+// split-fp32 GEMM over three-plane operands (gemm_split3.h).  a.K counts fp32 columns; a.lda / a.ldw count bf16 positions of
+// the x3 rows (>= 4 K); a.ldc counts floats (EPI_BIAS_F32) or bf16 positions of the x3 output rows (EPI_GELU_X3, >= 4 N)
+int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream);
+bool gemm_split3_ok(const GemmArgs& a);
+// x3 image [rows, 4 K bf16] of fp32 rows [rows, K]
+int launch_split3_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, hipStream_t stream);
 // which kernel `tile` = 0 resolves to: 1 / 2 = one-tile-per-workgroup 128x128 / 256x256, 3 = persistent pipelined
 int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile);
 
@@ -95,8 +105,9 @@ int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile)
 // qkv: T [n_seq * S, 3 * D] (q | k | v, heads of 64 inside each), out: T [n_seq * S, D]
 int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S, int heads, int causal,
                      hipStream_t stream);
-bool attention_x6_supported(int S, int causal);
-int launch_attention_x6(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream);
+// fp32 attention whose output is written as x3 rows [n_seq * S, 4 * heads * 64 bf16] (out_proj's operand in split-fp32 mode)
+bool attention_x3_supported(int S, int causal);
+int launch_attention_x3(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream);
 
 // --------------------------------------------------------------------------------------------- row ops
 // y[i] = LN(x[row(i)]) * gamma + beta.  row(i) = gather ? gather[i] : i; x row r at x + r * x_stride.
@@ -125,8 +136,6 @@ int launch_pool_normalize(const float* frame_emb, float* out, int n_clips, int f
 int launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t stream);
 int launch_group_mean(const float* in, float* out, int n_groups, int group, int dim, hipStream_t stream);
 int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream_t stream);
-// six-plane bf16 image [rows, 6 K] of fp32 rows [rows, K] (is_weight selects the weight-side plane order)
-int launch_split6(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int is_weight, hipStream_t stream);
 int launch_transpose_convert(const float* in, void* out, int out_kind, int rows, int cols, hipStream_t stream);
 int launch_wise(const float* a, const float* b, double w, float* out, size_t n, hipStream_t stream);
 

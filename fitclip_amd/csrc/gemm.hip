@@ -119,9 +119,7 @@ bool pipelined_ok(const GemmArgs& a) {
 template <typename T>
 int resolve_tile(int epi, const GemmArgs& a, int tile) {
   if (tile != 0) return tile;
-  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || (epi == EPI_DGELU_T && sizeof(T) == 4) ||
-                             ((epi == EPI_BIAS_F32 || epi == EPI_GELU_X6) && sizeof(T) == 2);
-  if ((epi == EPI_BIAS_F32 || epi == EPI_GELU_X6) && has_pipelined && pipelined_ok<T>(a)) return 3;  // the only kernel that has them
+  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || (epi == EPI_DGELU_T && sizeof(T) == 4);
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
   return t256 >= 512 ? 2 : 1;
@@ -130,17 +128,8 @@ int resolve_tile(int epi, const GemmArgs& a, int tile) {
 // tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (BIAS_T / GELU_T only)
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
-  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4) ||
-                                 ((EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X6) && sizeof(T) == 2);
+  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
-  if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X6) {  // split-fp32 epilogues: bf16 operands, pipelined kernel only
-    if constexpr (kHasPipelined) {
-      if (tile != 3 || !pipelined_ok<T>(a)) return fail(FC_EINVAL, "gemm: the split-fp32 epilogues need the pipelined kernel");
-      return launch_pipelined<T, EPI>(a, stream);
-    } else {
-      return fail(FC_EINVAL, "gemm: the split-fp32 epilogues take bf16 six-plane operands");
-    }
-  } else {
   if (tile == 3) {
     if constexpr (kHasPipelined) {
       if (!pipelined_ok<T>(a)) return fail(FC_EINVAL, "gemm: shape not supported by the pipelined kernel");
@@ -151,7 +140,6 @@ int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   }
   if (tile == 2) return launch_one<T, 256, 256, 2, 4, EPI>(a, stream);
   return launch_one<T, 128, 128, 2, 2, EPI>(a, stream);
-  }
 }
 
 template <typename T>
@@ -163,8 +151,8 @@ int launch_epi(int epi, const GemmArgs& a, int tile, hipStream_t stream) {
     case EPI_PATCH_F32: return launch_tile<T, EPI_PATCH_F32>(a, tile, stream);
     case EPI_STORE_F32: return launch_tile<T, EPI_STORE_F32>(a, tile, stream);
     case EPI_DGELU_T: return launch_tile<T, EPI_DGELU_T>(a, tile, stream);
-    case EPI_BIAS_F32: return launch_tile<T, EPI_BIAS_F32>(a, tile, stream);
-    case EPI_GELU_X6: return launch_tile<T, EPI_GELU_X6>(a, tile, stream);
+    case EPI_BIAS_F32:
+    case EPI_GELU_X3: return fail(FC_EINVAL, "gemm: epilogue %d belongs to the three-plane split-fp32 GEMM (fc_gemm_split3)", epi);
   }
   return fail(FC_EINVAL, "gemm: unknown epilogue %d", epi);
 }
@@ -184,8 +172,6 @@ int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStr
   if ((a.lda * esz) % 16 || (a.ldw * esz) % 16 || a.lda < a.K || a.ldw < a.K)
     return fail(FC_EINVAL, "gemm: lda=%d / ldw=%d must cover K and keep rows 16-byte aligned", a.lda, a.ldw);
   if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm: ldc=%d", a.ldc);
-  if (epilogue == EPI_GELU_X6 && (a.N % X6_CHUNK || a.ldc % 8 || a.ldc < X6_PLANES * a.N))
-    return fail(FC_EINVAL, "gemm: the six-plane epilogue needs N %% 32 == 0 and ldc >= 6 N (ldc=%d)", a.ldc);
   if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return fail(FC_EINVAL, "gemm: unaligned operand");
   if (epilogue != EPI_STORE_F32 && epilogue != EPI_PATCH_F32 && epilogue != EPI_DGELU_T && !a.bias)
     return fail(FC_EINVAL, "gemm: bias missing");

@@ -347,10 +347,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int RG = (BM + BN) / 8;
   constexpr int LPW = RG / NW;
-  constexpr bool kOutX6 = EPI == EPI_GELU_X6;         // six-plane bf16 rows (split-fp32 operand of the next GEMM)
-  constexpr bool kOutF32 = sizeof(T) == 4 || EPI == EPI_BIAS_F32;
-  constexpr bool kStaged = !kOutF32 && !kOutX6;       // bf16 outputs: LDS-transposed, 16-byte full-line stores
-  using TOUT = std::conditional_t<kOutF32, float, T>;
+  constexpr bool kOutF32 = sizeof(T) == 4;
+  constexpr bool kStaged = !kOutF32;                  // bf16 outputs: LDS-transposed, 16-byte full-line stores
+  using TOUT = T;
   constexpr int ROWP = TN * 2;                        // bytes per row of a wave's output patch (bf16)
   constexpr int CPR = ROWP / 16;                      // 16-byte chunks per patch row
   constexpr int PATCH = 16 * ROWP;                    // one 16-row pass of the wave tile
@@ -358,11 +357,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int IPP = 16 / RPI;                       // store instructions per pass
   constexpr int OFF_STG = 2 * STAGE;                  // NW patches
   constexpr int OFF_BIAS = OFF_STG + NW * 2048;       // 2 x 1 KiB   (f32 outputs: a 16-row x 128-byte patch per wave as well)
-  constexpr int NST = kStaged ? FM * IPP : kOutX6 ? FM * (FN / 2) * 6 : FM * FN;   // store instructions per wave per interior tile
+  constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
-  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4) ||
-                ((EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X6) && sizeof(T) == 2), "epilogue");
+  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4), "epilogue");
   // the counted wait behind the epilogue stores needs LPW + NST to fit the 6-bit vmcnt; tilings with more stores per wave
   // (4 waves of 128x128) wait for everything at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;
@@ -661,51 +659,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
               // kernel +6..18 % on the N >= 2304 shapes)
               __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(p));
             }
-          }
-        }
-      } else if constexpr (kOutX6) {
-        // six-plane output: the 16 x 32 patch of two column-adjacent fragments becomes 16 rows x 384 contiguous bytes
-        // [p1 p1 p2 p2 p1 p3]; the planes go through two 1 KiB halves of the wave's LDS patch (16 rows x 64 bytes,
-        // 16-byte chunk ^ (row >> 2) & 3) and leave as 8 rows x 128 bytes per store instruction: [p1 p1], [p2 p2], [p1 p3]
-        char* stg = smem + OFF_STG + wave * 2048;
-        const int rrow = lane >> 3, rk = lane & 7;
-        auto put = [&](char* plane, int jh, const bf16x4& v4) {
-          *reinterpret_cast<bf16x4*>(plane + r * 64 + (((jh * 2 + (q >> 1)) ^ ((r >> 2) & 3)) << 4) + ((q & 1) << 3)) = v4;
-        };
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-#pragma unroll
-          for (int jj = 0; jj < FN / 2; ++jj) {
-            bf16x4 p3[2];
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
-              f32x4 v = acc[i][2 * jj + jh];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
-              bf16x4 p1, p2;
-              split3(v, p1, p2, p3[jh]);
-              put(stg, jh, p1);
-              put(stg + 1024, jh, p2);
-            }
-            const int mo0 = cm0 + wm * TM + i * 16, group = (cn0 + wn * TN + jj * 32) / X6_CHUNK;
-            auto flush = [&](int first, const char* lo, const char* hi) {  // planes `first`, `first + 1` of the group
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const int row = h * 8 + rrow;
-                const char* src = (rk < 4 ? lo : hi) + row * 64 + (((rk & 3) ^ ((row >> 2) & 3)) << 4);
-                const bf16x8 val = *reinterpret_cast<const bf16x8*>(src);
-                if (interior || (mo0 + row < g.M && group * X6_CHUNK < g.N)) {
-                  bf16* dst = reinterpret_cast<bf16*>(g.C) + (size_t)(mo0 + row) * g.ldc +
-                              (size_t)group * (X6_CHUNK * X6_PLANES) + first * X6_CHUNK + rk * 8;
-                  __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(dst));
-                }
-              }
-            };
-            flush(0, stg, stg);                 // [p1 p1]
-            flush(2, stg + 1024, stg + 1024);   // [p2 p2]
-            put(stg + 1024, 0, p3[0]);          // p3 takes p2's half (LDS operations of a wave execute in order)
-            put(stg + 1024, 1, p3[1]);
-            flush(4, stg, stg + 1024);          // [p1 p3]
           }
         }
       } else {

@@ -1,0 +1,337 @@
+// Split-fp32 GEMM over THREE-plane operands (gfx950): fp32 results from the bf16 matrix cores, products formed from registers.
+//
+//   C[M,N] = epilogue(A[M,K] . W[N,K]^T)       A, W: fp32 values stored as three bf16 planes each ("x3" rows, common.h)
+//
+// An fp32 number is exactly p1 + p2 + p3 (bf16 each), and a product is recovered to 2^-26 from the six bf16 products
+// p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1.  The six-plane layout of round 2 spelled those six products out ALONG K
+// ([p1 p1 p2 p2 p1 p3] x [q1 q2 q1 q2 q3 q1], 12 bytes per value) so that an unmodified dot-product kernel formed them; here
+// every plane exists once (6 useful bytes per value): a K-step stages the three planes of 16 columns of both operands in
+// LDS, a wave reads each plane fragment ONCE and issues the six MFMAs from those registers - half the HBM / L2 / LDS-DMA
+// bytes and half the LDS fragment reads per fp32 FLOP.
+//
+// Operand rows ("x3", X3_* in common.h): every 16 fp32 columns are one 128-byte line [p1 x16 | p2 x16 | p3 x16 | 32 bytes
+// never read or written]; a K-step reads exactly one line of every tile row, of which the LDS-DMA lanes fetch the 96 bytes.
+//
+// Kernel: 256 x 256 output tile per workgroup of 8 waves (2 x 4; wave tile 128 x 64 = 4 x 2 MFMA tiles), persistent (one
+// workgroup per CU walks an XCD-contiguous tile list), v_mfma_f32_32x32x16_bf16 (k = 16 = one K-step).  THREE LDS stages of
+// 48 KiB in a ring: [512 tile rows][p1 | p2 | p3][32 bytes]; the 16-byte half h of a row-plane slot is stored at half
+// h ^ (row >> 3 & 1) (rows r and r + 8 would otherwise share banks: 96-byte rows), applied on the SOURCE side of the LDS-DMA
+// and on the fragment reads (same involution).  The DMA of K-step k + 3 is issued at the hand-over of step k, so every
+// operand line has two whole K-steps (~5 us) to arrive: measured in tools/split3_lab, the K loop's loss against its
+// no-load ablation is DMA latency (L2 / HBM), not DMA issue - issuing the pieces LATER (behind MFMA groups of the next step, as
+// the bf16 kernel's piece schedules do) made every shape slower, an XCD-local N range (nsplit) faster.  The three stages
+// leave no LDS for output patches, so the epilogue borrows the stage the tile's last K-step has just released (the DMA that
+// would refill it - K-step 2 of the next tile - waits for the barrier that ends the epilogue).
+// Hand-over in front of the last MFMA group, counted vmcnt behind the epilogue stores, LDS-transposed full-width stores: the
+// structure of gemm_pipelined_kernel (gemm_kernel.h), restated for this tile.
+#pragma once
+#include "gemm_kernel.h"
+
+namespace fc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// (activation plane, weight plane) of the six products p1q1 p1q2 p2q1 p2q2 p1q3 p3q1, in issue order
+constexpr int prod_a(int x) { return x == 2 || x == 3 ? 1 : (x == 5 ? 2 : 0); }
+constexpr int prod_w(int x) { return x == 1 || x == 3 ? 1 : (x == 4 ? 2 : 0); }
+
+// ABL (tools/split3_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 2 = every workgroup stages the operand
+// rows of tile (0, 0) (all loads hit L2); 3 = no epilogue; 5 = no loads and no
+// vmcnt waits in the K loop (the epilogue's stores drain unobserved); 6 = no loads, no waits, no epilogue (MFMA + LDS reads only)
+template <int EPI, int ABL = 0>
+__global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int TM = BM / WM, TN = BN / WN;        // 128 x 64 per wave
+  constexpr int FM = TM / 32, FN = TN / 32;        // 4 x 2 MFMA tiles of 32 x 32
+  constexpr int ROW3 = 96;                         // LDS bytes per tile row and K-step: three planes x 16 columns
+  constexpr int STAGE = (BM + BN) * ROW3;          // 49152
+  constexpr int LPA = BM * 6 / 64 / NW, LPB = BN * 6 / 64 / NW, LPW = LPA + LPB;  // LDS-DMA pieces per wave and stage: 3 + 3
+  constexpr int OFF_BIAS = 3 * STAGE;              // 2 x 1 KiB behind the three stages
+  constexpr int PATCH = STAGE / NW;                // 6 KiB of the released stage per wave during the epilogue
+  constexpr int ROWX = 112;                        // x3 patch row stride: 96 bytes of planes + 16 (2-way instead of 4-way write conflicts)
+  constexpr bool kOutX3 = EPI == EPI_GELU_X3;
+  constexpr int NST = kOutX3 ? FM * FN * 2 * 4 : FM * FN * 4;  // store instructions per wave and interior tile: 64 / 32
+  // the counted wait behind the epilogue stores needs 2 LPW + NST to fit the 6-bit vmcnt; the x3 epilogue (whole 128-byte lines:
+  // 64 stores) waits for its stores at the first hand-over of the next tile instead
+  constexpr bool kCounted = LPW + NST < 64;
+  static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X3, "epilogue");
+  static_assert(32 * ROWX <= PATCH && 32 * 128 <= PATCH, "output patch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- tile schedule: XCD x (= blockIdx & 7) owns a contiguous range of M-panels (optionally only 1 / nsplit of the N
+  // range); its workgroups stride through that range in N-fastest order (gemm_pipelined_kernel's schedule)
+  const int tilesN = (g.N + BN - 1) / BN;
+  const int tilesM = (g.M + BM - 1) / BM;
+  const int G = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  const int nblk = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+  const int ngrp = (g.nsplit > 1 && 8 % g.nsplit == 0 && tilesN % g.nsplit == 0 && G == 8 * (G >> 3)) ? g.nsplit : 1;
+  const int grp = xcd % ngrp, xi = xcd / ngrp, nx = 8 / ngrp;
+  const int pq = tilesM / nx, pr = tilesM % nx;
+  const int mp0 = xi < pr ? xi * (pq + 1) : pr * (pq + 1) + (xi - pr) * pq;
+  const int npanel = pq + (xi < pr ? 1 : 0);
+  const int tnn = tilesN / ngrp, tn0 = grp * tnn;
+  const int t_end = npanel * tnn;
+  int t = pos;
+  if (t >= t_end) return;
+
+  const int nk = g.K / X3_GROUP;                   // K-steps: one 128-byte line of every operand row each (even, >= 4)
+  const unsigned lda_b = (unsigned)g.lda * 2u, ldw_b = (unsigned)g.ldw * 2u;  // row strides in bytes (lda / ldw count bf16)
+  // K-steps of a tile are visited in a rotated order that only depends on the column tile: the workgroups that share an
+  // activation panel read different lines at any moment, and a row's result does not depend on the rows around it
+  int rot = 0;
+  unsigned offA[LPA], offB[LPB];
+  // piece i of this wave covers chunks (wave + 8 i) * 64 + lane of the [rows][6 chunks] image of its operand tile
+  auto tile_sources = [&](int tile, int& m0, int& n0) {
+    const int tm = mp0 + tile / tnn, tn = tn0 + tile % tnn;
+    m0 = tm * BM;
+    n0 = tn * BN;
+    // neighbouring column tiles run two K-steps apart (lab sweep 0 .. 16: 0 - 2 are 3 - 5 % faster than 5 or more - a line
+    // fetched for one column tile is still in L2 when the next one asks for it); g.nblock - 1 overrides it in the lab
+    rot = (tn * (g.nblock > 0 ? g.nblock - 1 : 2)) % nk;
+#pragma unroll
+    for (int i = 0; i < LPA; ++i) {
+      const int c6 = (wave + i * NW) * 64 + lane, row = c6 / 6, c = c6 - row * 6;
+      const int gr = min((ABL == 2 ? 0 : m0) + row, g.M - 1);
+      offA[i] = (unsigned)gr * lda_b + (unsigned)((c >> 1) * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < LPB; ++i) {
+      const int c6 = (wave + i * NW) * 64 + lane, row = c6 / 6, c = c6 - row * 6;
+      const int gr = min((ABL == 2 ? 0 : n0) + row, g.N - 1);
+      offB[i] = (unsigned)gr * ldw_b + (unsigned)((c >> 1) * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4));
+    }
+  };
+  auto stage_load = [&](int stage_off, int kt) {  // the wave's six pieces of K-step kt -> the stage at byte offset stage_off
+    kt += rot;
+    if (kt >= nk) kt -= nk;
+    char* dst = smem + stage_off + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < LPA; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[i] + (unsigned)kt * X3_GROUP_BYTES)),
+          (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < LPB; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[i] + (unsigned)kt * X3_GROUP_BYTES)),
+          (__attribute__((address_space(3))) void*)(dst + BM * ROW3 + i * NW * 1024), 16, 0, 0);
+  };
+  auto bias_load = [&](int buf, int n0) {  // BN floats -> LDS by one LDS-DMA of wave 0 (older than that tile's first K-step)
+    if (wave == 0) {
+      const float* p = g.bias + min(n0 + lane * 4, g.N - 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(smem + OFF_BIAS + buf * 1024), 16, 0, 0);
+    }
+  };
+
+  // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads the 16 bytes k = 8h .. 8h+7 of plane p of tile row r
+  const int r = lane & 31, h = lane >> 5;
+  const int hs = (h ^ ((r >> 3) & 1)) << 4;
+  const int a_base = (wm * TM + r) * ROW3 + hs;
+  const int b_base = (BM + wn * TN + r) * ROW3 + hs;
+  auto read_w = [&](const char* st, bf16x8 (&w)[3][FN]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) w[q][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * ROW3 + q * 32);
+  };
+  auto read_a = [&](const char* st, int i, bf16x8 (&a)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * ROW3 + p * 32);
+  };
+
+  int m0, n0;
+  tile_sources(t, m0, n0);
+  bias_load(0, n0);
+  // the ring: byte offsets of the stage being multiplied, the next one, and the one after (wave-uniform scalars)
+  int s_cur = 0, s_nxt = STAGE, s_aft = 2 * STAGE;
+  stage_load(s_cur, 0);
+  stage_load(s_nxt, 1);
+  stage_load(s_aft, 2);
+  bf16x8 wf[2][3][FN], af[2][3];
+  wait_vmcnt<2 * LPW>();  // the bias slice and K-step 0 of the first tile have landed
+  block_barrier();
+  read_w(smem + s_cur, wf[0]);
+  read_a(smem + s_cur, 0, af[0]);
+  int it = 0;                 // tile iteration (bias buffer = it & 1)
+  bool prev_counted = false;  // the previous tile issued exactly NST stores between its prefetches and K-step 2 of this one
+
+  for (;;) {
+    f32x16 acc[FM][FN];
+    {
+      // the accumulators start from the bias slice of this tile: register t of a lane is column (t & 3) + 8 (t >> 2) + 4 h
+      const float* biasb = reinterpret_cast<const float*>(smem + OFF_BIAS + (it & 1) * 1024) + wn * TN + 4 * h;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(biasb + j * 32 + gq * 8);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][gq * 4 + e] = b[e];
+        }
+      }
+    }
+    const int cm0 = m0, cn0 = n0;
+    const int tnext = t + nblk;
+    const bool has_next = tnext < t_end;
+
+    // one K-step; PAR = kt & 1 = fragment-register set of this step (nk is even, so a tile starts at parity 0)
+    auto kstep = [&](int kt, auto PAR) {
+      constexpr int par = decltype(PAR)::value;
+      const char* st = smem + s_cur;
+      static_for<FM>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u + 1 < FM) {
+          read_a(st, u + 1, af[(u + 1) & 1]);  // the next row tile's planes are requested before this group's MFMAs
+        } else {
+          // hand-over to the next K-step in front of the LAST group: every LDS read of this stage has been issued; once
+          // they have returned the stage may be refilled (with K-step kt + 3)
+          if constexpr (ABL != 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if constexpr (ABL < 5) {
+            // K-step kt + 1 must have landed.  Younger than it in this wave's queue: the pieces of K-step kt + 2 if that step
+            // exists, and - at the first step of a tile that follows a fully stored one - the NST epilogue stores in between
+            if (kCounted && kt == 0 && prev_counted) wait_vmcnt<kCounted ? NST + LPW : 0>();
+            else if (kt + 2 < nk || has_next) wait_vmcnt<LPW>();
+            else wait_vmcnt<0>();
+          }
+          if constexpr (ABL != 7 && ABL != 8) block_barrier();  // 7 / 8: no hand-over barrier (lab: what the barrier costs)
+          if (ABL != 1 && ABL < 5) {
+            if (kt + 3 < nk) {
+              stage_load(s_cur, kt + 3);
+            } else if (has_next) {
+              if (kt + 3 == nk) {
+                tile_sources(tnext, m0, n0);
+                bias_load((it + 1) & 1, n0);
+                stage_load(s_cur, 0);
+              } else if (kt + 2 == nk) {
+                stage_load(s_cur, 1);
+              }  // kt + 1 == nk: this stage is the epilogue's patch area; K-step 2 of the next tile follows the epilogue
+            }
+          }
+          // the first fragments of the next K-step, UNCONDITIONALLY (after the last step of the last tile they are never
+          // used): a branch around them would put them in a basic block of their own, in front of this group's first MFMA,
+          // and hipcc's lgkmcnt(0) for that MFMA's operands would then wait for their whole LDS latency
+          const char* nx = smem + s_nxt;
+          read_w(nx, wf[par ^ 1]);
+          read_a(nx, 0, af[0]);
+        }
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][prod_w(x)][j], af[u & 1][prod_a(x)], acc[u][j], 0, 0, 0);
+        // issue order inside a group: ONE MFMA, then the LDS reads of the next group, then the other MFMAs (hipcc would
+        // otherwise sink the reads next to their first use, and its wait for this group's operands would cover them)
+        constexpr int kReads = (u + 1 < FM) ? 3 : 3 + 3 * FN;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * FN - 1, 0);
+      });
+      const int released = s_cur;
+      s_cur = s_nxt;
+      s_nxt = s_aft;
+      s_aft = released;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      kstep(kt, std::integral_constant<int, 0>{});
+      kstep(kt + 1, std::integral_constant<int, 1>{});
+    }
+    // af[0] / wf[0] now hold the first fragments of the next tile; s_aft is the stage the last K-step released
+
+    const bool interior = cm0 + BM <= g.M && cn0 + BN <= g.N;
+    if constexpr (ABL == 3 || ABL >= 6) {
+      float keep = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+      if (keep == 123.456f) reinterpret_cast<float*>(g.C)[0] = keep;
+      prev_counted = false;
+    } else {
+      char* stg = smem + s_aft + wave * PATCH;
+      if constexpr (!kOutX3) {
+        // f32 outputs: a 32 x 32 tile goes through the wave's 32-row x 128-byte patch (chunk ^ (row & 7): conflict-free
+        // both ways) and leaves as 8 rows x 128 contiguous bytes per store instruction
+        const int rrow = lane >> 3, rch = lane & 7;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const f32x4 v = {acc[i][j][gq * 4], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]};
+              *reinterpret_cast<f32x4*>(stg + r * 128 + (((2 * gq + h) ^ (r & 7)) << 4)) = v;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int row = s * 8 + rrow;
+              const f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+              const int mo = cm0 + wm * TM + i * 32 + row, no = cn0 + wn * TN + j * 32 + rch * 4;
+              if (interior || (mo < g.M && no < g.N))
+                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)mo * g.ldc + no));
+            }
+          }
+        }
+      } else {
+        // x3 outputs (the next GEMM's activation operand): exact QuickGELU, then the three planes of 32 rows x 16 columns go
+        // through the wave's patch as [row][p1 | p2 | p3][32 bytes] and leave as WHOLE 128-byte lines, 8 rows per store
+        // instruction: chunk x = 8 row + c lands at byte 16 c of that row's line, c = 6, 7 are zeros (a line written only in
+        // part costs a read-modify-write at the memory side)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+#pragma unroll
+              for (int gh = 0; gh < 2; ++gh) {
+                const int gq = 2 * cg + gh;
+                f32x4 v = {acc[i][j][gq * 4], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
+                bf16x4 p1, p2, p3;
+                split3(v, p1, p2, p3);
+                char* w0 = stg + r * ROWX + gh * 16 + h * 8;
+                *reinterpret_cast<bf16x4*>(w0) = p1;
+                *reinterpret_cast<bf16x4*>(w0 + 32) = p2;
+                *reinterpret_cast<bf16x4*>(w0 + 64) = p3;
+              }
+              const int mo0 = cm0 + wm * TM + i * 32;
+              const int group = (cn0 + wn * TN + j * 32 + cg * 16) / X3_GROUP;
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                const int row = s * 8 + (lane >> 3), c = lane & 7;
+                bf16x8 val = {};
+                if (c < 6) val = *reinterpret_cast<const bf16x8*>(stg + row * ROWX + c * 16);
+                if (interior || (mo0 + row < g.M && group * X3_GROUP < g.N)) {
+                  char* dst = reinterpret_cast<char*>(g.C) + ((size_t)(mo0 + row) * g.ldc) * 2 + (size_t)group * X3_GROUP_BYTES + c * 16;
+                  __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(dst));
+                }
+              }
+            }
+          }
+        }
+      }
+      prev_counted = interior;
+    }
+    if (!has_next) break;
+    // the patch area becomes a stage again: once every wave is through with its patch, K-step 2 of the next tile goes there
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    block_barrier();
+    if (ABL != 1 && ABL < 5) stage_load(s_aft, 2);
+    ++it;
+    t = tnext;
+  }
+}
+
+}  // namespace
+}  // namespace fc

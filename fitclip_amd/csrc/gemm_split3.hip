@@ -1,0 +1,106 @@
+// Host-side dispatch of the three-plane split-fp32 GEMM (kernel: gemm_split3.h) and the fp32 -> x3 row converter.
+#include "gemm_split3.h"
+
+#include <algorithm>
+
+namespace fc {
+
+namespace {
+
+int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
+template <int EPI>
+int launch_one(const GemmArgs& a, hipStream_t stream) {
+  constexpr int lds = 3 * 512 * 96 + 2048;  // three stages (the epilogue borrows the released one) + two bias slices
+  auto kern = gemm_split3_kernel<EPI>;
+  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "gemm_split3: cannot raise dynamic LDS to %d bytes", lds);
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count())), dim3(512), lds, stream, a);
+  FC_CHECK_LAUNCH("gemm_split3");
+  return FC_OK;
+}
+
+// fp32 rows -> x3 rows: thread per (row, line of 16 columns, half): 8 values -> three 16-byte chunks (+ 16 zero bytes of the
+// line's unused quarter, so that every line is written whole)
+__global__ void __launch_bounds__(256) split3_rows_kernel(const float* __restrict__ in, long ld_in, char* __restrict__ out,
+                                                          long ld_out_bytes, long rows, int K) {
+  const long per_row = K / 8;  // 8-column pieces
+  const long total = rows * per_row;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / per_row;
+    const int piece = (int)(i - row * per_row), group = piece >> 1, half = piece & 1;
+    const float* src = in + row * ld_in + piece * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x4 a1, a2, a3, b1, b2, b3;
+    split3(lo, a1, a2, a3);
+    split3(hi, b1, b2, b3);
+    char* dst = out + row * ld_out_bytes + (long)group * X3_GROUP_BYTES + half * 16;
+    auto put = [&](char* p, const bf16x4& x, const bf16x4& y) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x[e]; v[4 + e] = y[e]; }
+      *reinterpret_cast<bf16x8*>(p) = v;
+    };
+    put(dst, a1, b1);
+    put(dst + 32, a2, b2);
+    put(dst + 64, a3, b3);
+    *reinterpret_cast<f32x4*>(dst + 96) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+}  // namespace
+
+bool gemm_split3_ok(const GemmArgs& a) {
+  return a.M > 0 && a.N > 0 && a.K >= 64 && a.K % 32 == 0 && a.N % 32 == 0 && a.bias != nullptr &&
+         ((uintptr_t)a.bias & 15) == 0 && (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);
+}
+
+int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail(FC_EINVAL, "gemm_split3: empty problem %dx%dx%d", a.M, a.N, a.K);
+  if (a.K % 32 || a.K < 64) return fail(FC_EINVAL, "gemm_split3: K=%d must be a multiple of 32, at least 64", a.K);
+  if (a.N % 32) return fail(FC_EINVAL, "gemm_split3: N=%d must be a multiple of 32", a.N);
+  const long need = x3_row_elems(a.K);
+  if (a.lda < need || a.ldw < need || a.lda % 64 || a.ldw % 64)
+    return fail(FC_EINVAL, "gemm_split3: lda=%d / ldw=%d must cover the %ld bf16 positions of an x3 row in whole 128-byte lines",
+                a.lda, a.ldw, need);
+  if (((uintptr_t)a.A | (uintptr_t)a.W) & 127 || ((uintptr_t)a.C & 15))
+    return fail(FC_EINVAL, "gemm_split3: operands must be 128-byte aligned (x3 rows are made of whole lines)");
+  if (!a.bias || ((uintptr_t)a.bias & 15)) return fail(FC_EINVAL, "gemm_split3: bias missing or unaligned");
+  if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32))
+    return fail(FC_EINVAL, "gemm_split3: an operand exceeds the 4 GiB of the kernel's 32-bit row offsets");
+  switch (epilogue) {
+    case EPI_BIAS_F32:
+      if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split3: ldc=%d", a.ldc);
+      return launch_one<EPI_BIAS_F32>(a, stream);
+    case EPI_GELU_X3:
+      if (a.ldc % 64 || a.ldc < x3_row_elems(a.N) || ((uintptr_t)a.C & 127))
+        return fail(FC_EINVAL, "gemm_split3: the x3 output needs 128-byte aligned rows of >= 4 N bf16 (ldc=%d)", a.ldc);
+      return launch_one<EPI_GELU_X3>(a, stream);
+  }
+  return fail(FC_EINVAL, "gemm_split3: epilogue %d", epilogue);
+}
+
+int launch_split3_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  if (K % X3_GROUP || ld_in % 4 || ld_out % 64 || ld_out < x3_row_elems(K) || ((uintptr_t)in & 15) || ((uintptr_t)out & 127))
+    return fail(FC_EINVAL, "split3_rows: K %% 16, alignment or row stride");
+  const long total = rows * (K / 8);
+  const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, stream, in, ld_in, static_cast<char*>(out), ld_out * 2,
+                     rows, K);
+  FC_CHECK_LAUNCH("split3_rows");
+  return FC_OK;
+}
+
+}  // namespace fc

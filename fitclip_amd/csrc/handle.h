@@ -18,8 +18,8 @@ struct WeightSlot {
 struct Block {
   const float *ln1_w, *ln1_b, *in_b, *out_b, *ln2_w, *ln2_b, *fc_b, *proj_b;
   const void *in_w, *out_w, *fc_w, *proj_w;  // element type T of the handle's precision, [N, K]
-  // split_gemm: six-plane bf16 images [N, 6 K] of the four weights (visual tower only)
-  const void *in_w6 = nullptr, *out_w6 = nullptr, *fc_w6 = nullptr, *proj_w6 = nullptr;
+  // split_gemm: x3 rows [N, 4 K bf16 positions] of the four weights (visual tower only; common.h)
+  const void *in_w3 = nullptr, *out_w3 = nullptr, *fc_w3 = nullptr, *proj_w3 = nullptr;
   // training: transposed copies [K, N] for the dgrad GEMMs (fc_train_prepare)
   const void *in_wT = nullptr, *out_wT = nullptr, *fc_wT = nullptr, *proj_wT = nullptr;
 };

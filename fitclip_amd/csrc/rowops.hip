@@ -25,52 +25,54 @@ template <> __device__ __forceinline__ void put4<bf16>(bf16* p, const f32x4& v) 
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-// Output kind "x6": a row of 6 D bf16, the six-plane image of D fp32 values (common.h, split-fp32 operands).  x6_t is a
-// 2-byte stand-in element so that row pointers and strides count bf16 elements.
-struct x6_t { bf16 v; };
-__device__ __forceinline__ void store_x6_activation(bf16* row_out, int col, const f32x4& x) {
-  bf16x4 p1, p2, p3;
-  split3(x, p1, p2, p3);
-  bf16* g = row_out + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
-  *reinterpret_cast<bf16x4*>(g) = p1;
-  *reinterpret_cast<bf16x4*>(g + X6_CHUNK) = p1;
-  *reinterpret_cast<bf16x4*>(g + 2 * X6_CHUNK) = p2;
-  *reinterpret_cast<bf16x4*>(g + 3 * X6_CHUNK) = p2;
-  *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p1;
-  *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p3;
+// Output kind "x3": a row of 4 D bf16 positions, the three-plane image of D fp32 values (common.h: every 16 columns one
+// 128-byte line [p1 x16 | p2 x16 | p3 x16 | 32 unused bytes]).  x3_t is a 2-byte stand-in element so that row pointers and
+// strides count bf16 positions.
+struct x3_t { bf16 v; };
+// Written by a FULL wave whose lanes 8k .. 8k + 7 hold the eight adjacent 4-column blocks of TWO 16-column lines (the
+// LayerNorm kernels: lane l has columns 4 l .. 4 l + 3 of every 256-column stripe).  The octet exchanges its planes with DPP
+// (quad_perm inside a quad, row_shr / row_shl by 4 between the two quads; no LDS) and writes each line WHOLE with one
+// store instruction - lane j of the octet stores chunk j of [p1 cols 0-7 | p1 8-15 | p2 0-7 | p2 8-15 | p3 0-7 | p3 8-15 | 0 | 0],
+// first of the even line, then of the odd one.  The last 32 bytes of a line carry no data, but a line written only in
+// part costs a read-modify-write at the memory side (the 96-byte form of this store ran the add+LayerNorm pass at 2.5 TB/s),
+// and half lines per instruction (a quad writing 64 bytes twice) reached 3.5 TB/s.
+template <int CTRL> __device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
-// The same image written by a FULL wave whose lanes 2k, 2k + 1 hold the adjacent column blocks c (c % 8 == 0) and c + 4
-// (the LayerNorm kernels): the two lanes exchange their planes (DPP quad_perm, no LDS) and each writes three 16-byte
-// chunks - the even lane plane slots 0, 2, 4, the odd lane slots 1, 3, 5 - so one store instruction covers 128
-// contiguous bytes per 32-column group instead of 64 in 8-byte pieces.
-__device__ __forceinline__ unsigned lane_xor1(unsigned v) {
-  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
-}
-__device__ __forceinline__ void store_x6_paired(bf16* row_out, int col, const f32x4& x, int lane) {
+__device__ __forceinline__ void store_x3_octet(bf16* row_out, int col, const f32x4& x, int lane) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   bf16x4 p1, p2, p3;
   split3(x, p1, p2, p3);
   const u32x2 a1 = __builtin_bit_cast(u32x2, p1), a2 = __builtin_bit_cast(u32x2, p2), a3 = __builtin_bit_cast(u32x2, p3);
-  const u32x2 b1 = {lane_xor1(a1[0]), lane_xor1(a1[1])}, b2 = {lane_xor1(a2[0]), lane_xor1(a2[1])},
-              b3 = {lane_xor1(a3[0]), lane_xor1(a3[1])};
-  const bool odd = lane & 1;
-  auto chunk = [&](const u32x2& own, const u32x2& other) {  // 8 columns in column order
-    return odd ? u32x4{other[0], other[1], own[0], own[1]} : u32x4{own[0], own[1], other[0], other[1]};
+  // inside a quad: lane jq takes its first 8 bytes from quad lane {0, 2, 0, 2}[jq] and its second 8 bytes from {1, 3, 1, 3}[jq],
+  // i.e. it holds columns 8 (jq & 1) .. + 7 of its quad's line, of every plane
+  auto gather = [&](const u32x2& v) {
+    return u32x4{dpp_mov<0x88>(v[0]), dpp_mov<0x88>(v[1]), dpp_mov<0xDD>(v[0]), dpp_mov<0xDD>(v[1])};
   };
-  const int c8 = col & ~7;
-  bf16* g = row_out + (c8 / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (c8 % X6_CHUNK) + (odd ? X6_CHUNK : 0);
-  *reinterpret_cast<u32x4*>(g) = chunk(a1, b1);                                        // slots 0 / 1: p1
-  *reinterpret_cast<u32x4*>(g + 2 * X6_CHUNK) = chunk(a2, b2);                         // slots 2 / 3: p2
-  *reinterpret_cast<u32x4*>(g + 4 * X6_CHUNK) = odd ? chunk(a3, b3) : chunk(a1, b1);   // slot 4: p1, slot 5: p3
+  auto shift = [&](const u32x4& v, auto CTRL) {
+    constexpr int ctrl = decltype(CTRL)::value;
+    return u32x4{dpp_mov<ctrl>(v[0]), dpp_mov<ctrl>(v[1]), dpp_mov<ctrl>(v[2]), dpp_mov<ctrl>(v[3])};
+  };
+  const u32x4 g1 = gather(a1), g2 = gather(a2), g3 = gather(a3);
+  const u32x4 lo3 = shift(g3, std::integral_constant<int, 0x114>{});  // row_shr:4 - lanes 4, 5: the even line's p3 chunks
+  const u32x4 hi1 = shift(g1, std::integral_constant<int, 0x104>{});  // row_shl:4 - lanes 0, 1: the odd line's p1 chunks
+  const u32x4 hi2 = shift(g2, std::integral_constant<int, 0x104>{});  //             lanes 2, 3: the odd line's p2 chunks
+  const int j = lane & 7;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  const u32x4 even = j < 2 ? g1 : (j < 4 ? g2 : (j < 6 ? lo3 : zero));
+  const u32x4 odd = j < 2 ? hi1 : (j < 4 ? hi2 : (j < 6 ? g3 : zero));
+  char* line = reinterpret_cast<char*>(row_out) + ((col & ~31) / X3_GROUP) * X3_GROUP_BYTES + j * 16;
+  *reinterpret_cast<u32x4*>(line) = even;
+  *reinterpret_cast<u32x4*>(line + X3_GROUP_BYTES) = odd;
 }
 // 4 columns starting at column c of an output row (called by every lane of the wave, lane l on columns .. + 4 l)
 template <typename OutT> __device__ __forceinline__ void put4_at(OutT* row, int c, const f32x4& v) { put4<OutT>(row + c, v); }
-template <> __device__ __forceinline__ void put4_at<x6_t>(x6_t* row, int c, const f32x4& v) {
-  store_x6_paired(reinterpret_cast<bf16*>(row), c, v, (int)(threadIdx.x & 63));
+template <> __device__ __forceinline__ void put4_at<x3_t>(x3_t* row, int c, const f32x4& v) {
+  store_x3_octet(reinterpret_cast<bf16*>(row), c, v, (int)(threadIdx.x & 63));
 }
 template <typename OutT> constexpr int kOutCols = 1;       // output elements per input column
-template <> constexpr int kOutCols<x6_t> = X6_PLANES;
+template <> constexpr int kOutCols<x3_t> = X3_GROUP_BYTES / 2 / X3_GROUP;  // 4 bf16 positions per column
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // One wave per row, the row lives in registers (D / 64 floats per lane), two-pass mean / centred variance in fp32
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
         const int c = V4 * 256 + i * 64 + lane;
-        if constexpr (!std::is_same_v<OutT, x6_t>) put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+        if constexpr (!std::is_same_v<OutT, x3_t>) put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
       }
     }
   }
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(256) layernorm_pair_kernel(float* __restrict__
         const int c = V4 * 256 + i * 64 + lane;
         s[i] = s[i] * rstd * gamma[c] + beta[c];
         if (pass == 0) xr[c] = s[i];
-        else if constexpr (!std::is_same_v<OutT, x6_t>) put<OutT>(y + (long)row * D + c, s[i]);
+        else if constexpr (!std::is_same_v<OutT, x3_t>) put<OutT>(y + (long)row * D + c, s[i]);
       }
     }
   }
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
         const int c = V4 * 256 + i * 64 + lane;
-        if constexpr (!std::is_same_v<YT, x6_t>) put<YT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+        if constexpr (!std::is_same_v<YT, x3_t>) put<YT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
       }
     }
   }
@@ -302,10 +304,10 @@ int add_layernorm_dispatch(float* x, long xs, const void* delta, long ds, const 
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   const T* dl = reinterpret_cast<const T*>(delta);
   YT* yo = reinterpret_cast<YT*>(y);
-  constexpr bool kX6 = std::is_same_v<YT, x6_t>;
+  constexpr bool kX3 = std::is_same_v<YT, x3_t>;
 #define FC_ADDLN(W) hipLaunchKernelGGL((add_layernorm_kernel<W, T, YT>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out)
   switch (D) {
-    case 128: if constexpr (kX6) return fail(FC_EINVAL, "add_layernorm: six-plane output needs a width that is a multiple of 256"); else FC_ADDLN(128); break;
+    case 128: if constexpr (kX3) return fail(FC_EINVAL, "add_layernorm: three-plane output needs a width that is a multiple of 256"); else FC_ADDLN(128); break;
     case 256: FC_ADDLN(256); break;
     case 512: FC_ADDLN(512); break;
     case 768: FC_ADDLN(768); break;
@@ -324,7 +326,7 @@ int layernorm_dispatch(const float* x, long xs, const int* gather, const float* 
   OutT* yo = reinterpret_cast<OutT*>(y);
   switch (D) {
     case 128:
-      if constexpr (std::is_same_v<OutT, x6_t>) return fail(FC_EINVAL, "layernorm: six-plane output needs a width that is a multiple of 256");
+      if constexpr (std::is_same_v<OutT, x3_t>) return fail(FC_EINVAL, "layernorm: three-plane output needs a width that is a multiple of 256");
       else hipLaunchKernelGGL((layernorm_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows);
       break;
     case 256: hipLaunchKernelGGL((layernorm_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
@@ -543,32 +545,6 @@ __global__ void __launch_bounds__(256) convert_kernel(const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) put<OutT>(out + n4 * 4 + threadIdx.x, in[n4 * 4 + threadIdx.x]);
 }
 
-// Six-plane bf16 image of fp32 rows (common.h, "split-fp32 operands"): every group of 32 columns becomes 192 bf16,
-// [p1 p1 p2 p2 p1 p3] for an activation (is_weight = 0) and [p1 p2 p1 p2 p3 p1] for a weight.  Thread = 4 columns.
-// A device helper the LayerNorm / attention kernels share when they write this image themselves.
-__global__ void __launch_bounds__(256) split6_kernel(const float* __restrict__ in, long ld_in, bf16* __restrict__ out,
-                                                     long ld_out, long rows, int K, int is_weight) {
-  const long per_row = K / 4, total = rows * per_row;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long row = i / per_row;
-    const int col = (int)(i - row * per_row) * 4;
-    const f32x4 x = *reinterpret_cast<const f32x4*>(in + row * ld_in + col);
-    if (!is_weight) {
-      store_x6_activation(out + row * ld_out, col, x);
-    } else {
-      bf16x4 p1, p2, p3;
-      split3(x, p1, p2, p3);
-      bf16* g = out + row * ld_out + (col / X6_CHUNK) * (X6_CHUNK * X6_PLANES) + (col % X6_CHUNK);
-      *reinterpret_cast<bf16x4*>(g) = p1;
-      *reinterpret_cast<bf16x4*>(g + X6_CHUNK) = p2;
-      *reinterpret_cast<bf16x4*>(g + 2 * X6_CHUNK) = p1;
-      *reinterpret_cast<bf16x4*>(g + 3 * X6_CHUNK) = p2;
-      *reinterpret_cast<bf16x4*>(g + 4 * X6_CHUNK) = p3;
-      *reinterpret_cast<bf16x4*>(g + 5 * X6_CHUNK) = p1;
-    }
-  }
-}
-
 // out[c, r] = in[r, c]  (weight packing of visual.proj / text_projection: [K, N] -> [N, K]); tiny, run once.
 template <typename OutT>
 __global__ void __launch_bounds__(256) transpose_convert_kernel(const float* __restrict__ in, OutT* __restrict__ out,
@@ -618,7 +594,7 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
   if (rows <= 0) return FC_OK;
   if ((x_stride % 4) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
     return fail(FC_EINVAL, "layernorm: operands must be 16-byte aligned");
-  if (out_kind == KIND_X6) return layernorm_dispatch<x6_t>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
+  if (out_kind == KIND_X3) return layernorm_dispatch<x3_t>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
   return out_kind == 1 ? layernorm_dispatch<bf16>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream)
                        : layernorm_dispatch<float>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
 }
@@ -630,7 +606,7 @@ int layernorm_pair_dispatch(float* x, const float* cls, const float* pos0, int t
   OutT* yo = reinterpret_cast<OutT*>(y);
   switch (D) {
     case 128:
-      if constexpr (std::is_same_v<OutT, x6_t>) return fail(FC_EINVAL, "layernorm_pair: six-plane output needs a width that is a multiple of 256");
+      if constexpr (std::is_same_v<OutT, x3_t>) return fail(FC_EINVAL, "layernorm_pair: three-plane output needs a width that is a multiple of 256");
       else hipLaunchKernelGGL((layernorm_pair_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows);
       break;
     case 256: hipLaunchKernelGGL((layernorm_pair_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
@@ -651,7 +627,7 @@ int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tok
       (((uintptr_t)x | (uintptr_t)cls | (uintptr_t)pos0 | (uintptr_t)g0 | (uintptr_t)b0 | (uintptr_t)g1 | (uintptr_t)b1 |
         (uintptr_t)y) & 15))
     return fail(FC_EINVAL, "layernorm_pair: operands must be 16-byte aligned");
-  if (out_kind == KIND_X6) return layernorm_pair_dispatch<x6_t>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
+  if (out_kind == KIND_X3) return layernorm_pair_dispatch<x3_t>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
   return out_kind == 1 ? layernorm_pair_dispatch<bf16>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream)
                        : layernorm_pair_dispatch<float>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
 }
@@ -660,11 +636,11 @@ int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stri
                          const float* gamma, const float* beta, void* y, long y_stride, int kind, int rows, int D,
                          int write_x, int delta_compact, hipStream_t stream, float* x_out) {
   if (rows <= 0) return FC_OK;
-  if (kind == KIND_X6) {  // delta fp32 (a split-fp32 GEMM's output), y the six-plane image of the LayerNorm output
-    if ((x_stride % 4) || (d_stride % 4) || (y_stride % 8) || y_stride < (long)X6_PLANES * D ||
+  if (kind == KIND_X3) {  // delta fp32 (a split-fp32 GEMM's output), y the three-plane image of the LayerNorm output
+    if ((x_stride % 4) || (d_stride % 4) || (y_stride % 64) || y_stride < x3_row_elems(D) ||
         (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta | (uintptr_t)x_out) & 15))
       return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned");
-    return add_layernorm_dispatch<float, x6_t>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows, D,
+    return add_layernorm_dispatch<float, x3_t>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows, D,
                                                write_x, delta_compact, x_out, stream);
   }
   const int esz = kind == 1 ? 2 : 4;
@@ -777,17 +753,6 @@ int launch_convert(const float* in, void* out, int out_kind, size_t n, hipStream
   else
     hipLaunchKernelGGL(convert_kernel<float>, dim3(blocks), dim3(256), 0, stream, in, (float*)out, n4, n);
   FC_CHECK_LAUNCH("convert");
-  return FC_OK;
-}
-
-int launch_split6(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int is_weight, hipStream_t stream) {
-  if (rows <= 0 || K <= 0) return FC_OK;
-  if (K % X6_CHUNK || ld_in % 4 || ld_in < K || ld_out % 8 || ld_out < (long)X6_PLANES * K ||
-      (((uintptr_t)in | (uintptr_t)out) & 15))
-    return fail(FC_EINVAL, "split6: K=%d must be a multiple of 32, rows 16-byte aligned, ld_out >= 6 K", K);
-  hipLaunchKernelGGL(split6_kernel, dim3(flat_blocks((size_t)rows * (K / 4))), dim3(256), 0, stream, in, ld_in, (bf16*)out,
-                     ld_out, rows, K, is_weight);
-  FC_CHECK_LAUNCH("split6");
   return FC_OK;
 }
 

@@ -7,11 +7,17 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X6, EPI_PATCH_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
+from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X3, EPI_PATCH_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
                    PREC_BF16, PREC_F32)
 
 _KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
-KIND_X6 = 2  # element-kind argument of the row kernels / attention: six-plane bf16 output (csrc/common.h)
+KIND_X3 = 3  # element-kind argument of the row kernels / attention: x3 rows out (three bf16 planes, csrc/common.h)
+
+
+def _x3_empty(rows: int, cols: int, device) -> torch.Tensor:
+    """x3 rows for `cols` fp32 columns: [rows, 4 cols] bf16 positions (every 16 columns one 128-byte line [p1 | p2 | p3 |
+    32 bytes no kernel reads or writes]).  Zero-filled so that two images of the same values compare equal."""
+    return torch.zeros((rows, 4 * cols), dtype=torch.bfloat16, device=device)
 
 
 def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -42,7 +48,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if epilogue == EPI_RESID_F32:
             raise ValueError("the residual epilogue accumulates into `out`")
         rows = M + M // patches if epilogue == EPI_PATCH_F32 else M
-        cols = 6 * N if epilogue == EPI_GELU_X6 else N  # six bf16 planes per column (split6)
+        if epilogue in (EPI_BIAS_F32, EPI_GELU_X3):
+            raise ValueError("the split-fp32 epilogues belong to gemm_split3")
+        cols = N
         out = torch.empty((rows, cols), dtype=torch.float32 if f32_out else a.dtype, device=a.device)
     _dev(out, "out", torch.float32 if f32_out else a.dtype)
     with torch.cuda.device(a.device):
@@ -63,57 +71,84 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
         rows = gather.numel()
     elif rows is None:
         rows = x.numel() // row_stride
-    six = out_dtype == "x6"  # six-plane bf16 rows (split6 layout)
-    y = torch.empty((rows, 6 * D if six else D), dtype=torch.bfloat16 if six else out_dtype, device=x.device)
+    x3 = out_dtype == "x3"  # three-plane rows (split3 layout)
+    y = _x3_empty(rows, D, x.device) if x3 else torch.empty((rows, D), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().fc_layernorm(x.data_ptr(), row_stride, _ptr(gather), gamma.data_ptr(), beta.data_ptr(),
-                                            y.data_ptr(), y.shape[1], KIND_X6 if six else _KIND[out_dtype], rows, D,
+                                            y.data_ptr(), y.shape[1], KIND_X3 if x3 else _KIND[out_dtype], rows, D,
                                             _lib.current_stream()), "fc_layernorm")
     return y
 
 
 def add_layernorm(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                  write_x: bool = True, six_plane: bool = False) -> torch.Tensor:
-    """x += delta (in place, if write_x); returns LayerNorm(x + delta) in delta's dtype, or (`six_plane`, fp32 delta) as
-    six-plane bf16 rows [rows, 6 D] (split6 layout)."""
-    _dev(x, "x", torch.float32), _dev(delta, "delta", torch.float32 if six_plane else None), _dev(gamma, "gamma", torch.float32)
+                  write_x: bool = True, three_plane: bool = False) -> torch.Tensor:
+    """x += delta (in place, if write_x); returns LayerNorm(x + delta) in delta's dtype, or (`three_plane`, fp32 delta) as
+    x3 rows [rows, 4 D] (split3 layout)."""
+    _dev(x, "x", torch.float32), _dev(delta, "delta", torch.float32 if three_plane else None), _dev(gamma, "gamma", torch.float32)
     rows, D = x.shape
-    y = torch.empty((rows, 6 * D if six_plane else D), dtype=torch.bfloat16 if six_plane else delta.dtype, device=x.device)
+    y = _x3_empty(rows, D, x.device) if three_plane else torch.empty((rows, D), dtype=delta.dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().fc_add_layernorm(x.data_ptr(), D, delta.data_ptr(), D, None, gamma.data_ptr(),
                                                 beta.data_ptr(), y.data_ptr(), y.shape[1],
-                                                KIND_X6 if six_plane else _KIND[delta.dtype], rows, D,
+                                                KIND_X3 if three_plane else _KIND[delta.dtype], rows, D,
                                                 int(write_x), _lib.current_stream()), "fc_add_layernorm")
     return y
 
 
 def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False,
-              six_plane: bool = False) -> torch.Tensor:
-    """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]; `six_plane`
-    (float32 qkv, non-causal, 113..224 tokens): six-plane bf16 rows [.., 6 * heads * 64] of the fp32 result."""
-    _dev(qkv, "qkv", torch.float32 if six_plane else None)
+              three_plane: bool = False) -> torch.Tensor:
+    """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]; `three_plane`
+    (float32 qkv, non-causal, 113..224 tokens): x3 rows [.., 4 * heads * 64] of the fp32 result."""
+    _dev(qkv, "qkv", torch.float32 if three_plane else None)
     D = heads * 64
     if qkv.shape != (n_seq * seq_len, 3 * D):
         raise ValueError(f"qkv shape {tuple(qkv.shape)} != {(n_seq * seq_len, 3 * D)}")
-    out = torch.empty((n_seq * seq_len, 6 * D if six_plane else D), dtype=torch.bfloat16 if six_plane else qkv.dtype,
-                      device=qkv.device)
+    out = (_x3_empty(n_seq * seq_len, D, qkv.device) if three_plane
+           else torch.empty((n_seq * seq_len, D), dtype=qkv.dtype, device=qkv.device))
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().fc_attention(KIND_X6 if six_plane else _KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(),
+        _lib.check(_lib.load().fc_attention(KIND_X3 if three_plane else _KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(),
                                             n_seq, seq_len, heads, int(causal), _lib.current_stream()), "fc_attention")
     return out
 
 
-def split6(x: torch.Tensor, weight: bool = False) -> torch.Tensor:
-    """Six-plane bf16 image [rows, 6 K] of fp32 rows [rows, K] (fc_split6): x = p1 + p2 + p3 exactly; every 32 columns
-    become [p1 p1 p2 p2 p1 p3] (activations) or [p1 p2 p1 p2 p3 p1] (`weight`), so a bf16 GEMM over the 6 K columns
-    (epilogues EPI_BIAS_F32 / EPI_GELU_X6) reproduces the fp32 product."""
+def split3(x: torch.Tensor) -> torch.Tensor:
+    """x3 rows [rows, 4 K bf16 positions] of fp32 rows [rows, K] (fc_split3): x = p1 + p2 + p3 exactly in three bf16 numbers;
+    every 16 columns become one 128-byte line [p1 x16 | p2 x16 | p3 x16 | 32 unused bytes].  Operand format of `gemm_split3`
+    (activations and weights alike)."""
     _dev(x, "x", torch.float32)
-    if x.dim() != 2 or x.shape[1] % 32:
-        raise ValueError("split6 needs [rows, K] with K a multiple of 32")
-    out = torch.empty((x.shape[0], 6 * x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    if x.dim() != 2 or x.shape[1] % 16:
+        raise ValueError("split3 needs [rows, K] with K a multiple of 16")
+    out = _x3_empty(x.shape[0], x.shape[1], x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().fc_split6(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
-                                         int(weight), _lib.current_stream()), "fc_split6")
+        _lib.check(_lib.load().fc_split3(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                                         _lib.current_stream()), "fc_split3")
+    return out
+
+
+def x3_planes(x3: torch.Tensor):
+    """The three planes [rows, K] (bfloat16) of x3 rows [rows, 4 K] (a view per plane; test / lab helper)."""
+    v = x3.view(x3.shape[0], -1, 4, 16)
+    return tuple(v[:, :, i].reshape(x3.shape[0], -1) for i in range(3))
+
+
+def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, epilogue: int = EPI_BIAS_F32) -> torch.Tensor:
+    """epilogue(A @ W^T) for x3 operands a3 [M, 4 K], w3 [N, 4 K] (`split3` images or the x3 outputs of LayerNorm / attention
+    / a previous EPI_GELU_X3 GEMM): six bf16 MFMA products per fp32 product, fp32 accumulate (fc_gemm_split3).
+    EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X3 -> x3 rows [M, 4 N] of QuickGELU(A @ W^T + bias)."""
+    _dev(a3, "a3", torch.bfloat16), _dev(w3, "w3", torch.bfloat16), _dev(bias, "bias", torch.float32)
+    if a3.dim() != 2 or w3.dim() != 2 or a3.shape[1] != w3.shape[1] or a3.shape[1] % 64:
+        raise ValueError(f"x3 operands need matching [rows, 4 K] shapes, got {tuple(a3.shape)} and {tuple(w3.shape)}")
+    M, N, K = a3.shape[0], w3.shape[0], a3.shape[1] // 4
+    if epilogue == EPI_GELU_X3:
+        out = _x3_empty(M, N, a3.device)
+    elif epilogue == EPI_BIAS_F32:
+        out = torch.empty((M, N), dtype=torch.float32, device=a3.device)
+    else:
+        raise ValueError("gemm_split3 has the epilogues EPI_BIAS_F32 and EPI_GELU_X3")
+    with torch.cuda.device(a3.device):
+        _lib.check(_lib.load().fc_gemm_split3(epilogue, a3.data_ptr(), w3.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K,
+                                              a3.stride(0), w3.stride(0), out.stride(0), _lib.current_stream()),
+                   "fc_gemm_split3")
     return out
 
 

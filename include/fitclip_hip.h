@@ -74,11 +74,11 @@ typedef struct {
                                  out_proj, LayerNorm 2 and the MLP - nothing else is read afterwards; identical
                                  embeddings, 6 % fewer FLOPs.  0 (default): every row, as the reference computes it */
   int32_t split_gemm;         /* fp32 precision only.  1: the four block GEMMs of the VISUAL tower run on the bf16 matrix
-                                 cores over split-fp32 ("six-plane") operands - every fp32 value as three bf16 numbers,
-                                 every product as six bf16 products accumulated in fp32 (fc_split6) - at fp32 accuracy
-                                 and ~1.5x the fp32-MFMA rate; LayerNorm, attention, residual stream, patch embedding,
-                                 the text tower and passes too small for the pipelined GEMM stay on the plain fp32
-                                 path.  0 (default): fp32-input MFMA everywhere */
+                                 cores over split-fp32 operands - every fp32 value as three bf16 numbers ("x3" rows,
+                                 fc_split3), every product as six bf16 products accumulated in fp32 (fc_gemm_split3) -
+                                 at fp32 accuracy and ~1.6x the fp32-MFMA rate; LayerNorm, attention, residual stream,
+                                 patch embedding, the text tower and passes too small for that GEMM stay on the plain
+                                 fp32 path.  0 (default): fp32-input MFMA everywhere */
 } fc_config;
 #define FC_CONFIG_INIT {(int32_t)sizeof(fc_config)}
 
@@ -163,24 +163,29 @@ FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather,
                  void* y, int64_t y_stride, int32_t out_kind, int32_t rows, int32_t D, fc_stream stream);
 /* v = x[r] + delta[r]; if write_x: x[r] = v; y[i] = LayerNorm(v) * gamma + beta, r = gather ? gather[i] : i.  The
  * residual update of a pre-LN block (slip.py:382-385) folded into the LayerNorm that follows it.  delta and y have
- * element kind `kind`; kind 2: delta fp32, y six-plane bf16 rows (fc_split6 layout, y_stride >= 6 D; fc_layernorm too). */
+ * element kind `kind`; kind 3: delta fp32, y x3 rows (fc_split3 layout, y_stride >= 4 D bf16 positions, 128-byte aligned;
+ * fc_layernorm too). */
 FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64_t d_stride, const int32_t* gather,
                      const float* gamma, const float* beta, void* y, int64_t y_stride, int32_t kind, int32_t rows,
                      int32_t D, int32_t write_x, fc_stream stream);
 /* Multi-head attention over packed rows: qkv [n_seq * S, 3 * heads * 64] (q | k | v, head dim 64) -> out
  * [n_seq * S, heads * 64], softmax(q k^T / 8 [+ causal mask]) v per (sequence, head), as nn.MultiheadAttention inside
  * slip.py:366-380.  Any S in fp32; bf16: causal up to 224 tokens, non-causal any S (K/V streamed beyond 224).
- * precision 2: fp32 qkv in, six-plane bf16 rows out (fc_split6 layout; non-causal, 113..224 tokens). */
+ * precision 3: fp32 qkv in, x3 rows out (fc_split3 layout; non-causal, 113..224 tokens). */
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
-/* Split-fp32 operand image: fp32 rows [rows, K] (row stride ld_in) -> bf16 [rows, 6 K] (row stride ld_out).  x = p1 + p2 + p3
- * exactly in three bf16 numbers; every 32 columns become [p1 p1 p2 p2 p1 p3] (activation side, is_weight = 0) or
- * [p1 p2 p1 p2 p3 p1] (weight side), so that a bf16 GEMM over the 6 K columns accumulates the six products that recover
- * the fp32 product to 2^-26 (fc_gemm epilogues 6 = fp32 output, 7 = QuickGELU + six-plane output).  Replaces nothing in
- * the reference: it is how this library reproduces the reference's fp32 `F.linear` on the bf16 matrix cores. */
-FC_API int fc_split6(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t is_weight,
-              fc_stream stream);
+/* Split-fp32 operands ("x3" rows): fp32 rows [rows, K] (row stride ld_in floats) -> three bf16 planes per value, x = p1 + p2
+ * + p3 exactly.  Every 16 columns become one 128-byte line [p1 x16 | p2 x16 | p3 x16 | 32 unused bytes]; a row is K / 16 lines
+ * = 4 K bf16 positions (ld_out counts bf16 positions, a multiple of 64; `out` 128-byte aligned).  K % 16 == 0. */
+FC_API int fc_split3(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, fc_stream stream);
+/* C = epilogue(A . W^T) over x3 operands A3 [M, K], W3 [N, K] (lda / ldw in bf16 positions, >= 4 K): the six bf16 products
+ * p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1 of every fp32 product, formed from registers on v_mfma_f32_32x32x16_bf16 and
+ * accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-26 per product, at the bf16 matrix cores'
+ * rate.  epilogue 6: C fp32 [M, N] = acc + bias (ldc floats); epilogue 7: C x3 rows [M, 4 N] = planes(QuickGELU(acc + bias))
+ * (ldc bf16 positions), the next GEMM's A operand.  K % 32 == 0, K >= 64, N % 32 == 0; operands below 4 GiB. */
+FC_API int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, const float* bias, void* C, int32_t M, int32_t N,
+                   int32_t K, int32_t lda, int32_t ldw, int32_t ldc, fc_stream stream);
 
 /* ---- training: the KD fine-tuning step of the student -------------------------------------------
  * Replaces autograd + torch.optim.AdamW for `TeacherStudentLightningModule.training_step / training_step_end /

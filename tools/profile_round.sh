@@ -34,12 +34,12 @@ elif [ "$prec" = bf16 ]; then
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi0E|365|1e9|$rows|768|3072|bias"
 else
-  # fp32x6 = the split-fp32 leg of the fp32 bench run (passes of 512 frames; six-plane operands: K' = 6 K): c_fc with the
-  # QuickGELU + six-plane epilogue has its own instantiation (epilogue 7); c_proj shares epilogue 6 with QKV / out_proj
-  # and is the only one of them above 2 ms (QKV 1.75, out_proj 0.6)
+  # fp32x6 = the split-fp32 leg of the fp32 bench run (passes of 512 frames; three-plane operands, six bf16 products per
+  # fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation (epilogue 7); c_proj
+  # shares epilogue 6 with QKV / out_proj and is the only one of them above 1.95 ms (QKV 1.7, out_proj 0.6)
   steps=3; chunk=512; rows=$((chunk * 197))
-  spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi7E|2000|1e9|$rows|3072|4608|bias_quickgelu_six_plane_out"
-  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi6E|2050|1e9|$rows|768|18432|bias_f32_out"
+  spec_fc="gemm_split3_kernel<7,|1900|1e9|$rows|3072|4608|bias_quickgelu_x3_out"
+  spec_proj="gemm_split3_kernel<6,|1950|1e9|$rows|768|18432|bias_f32_out"
 fi
 if [ "$prec" = fp32x6 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
