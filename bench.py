@@ -415,7 +415,8 @@ def run_split_mode(sd, video, text, args, shards, device, backend):
     from fitclip_amd.clip_model import build_clip
     from fitclip_amd.encoder import ClipVideoTextEncoder
 
-    enc = ClipVideoTextEncoder(build_clip(sd, precision="fp32x6", device=device), num_frames=args.frames)
+    enc = ClipVideoTextEncoder(build_clip(sd, precision="fp32x6", device=device, chunk_frames=args.split_chunk_frames),
+                               num_frames=args.frames)
     n_local = shards.n_local
     step = make_step(enc, video, text, shards)
     for _ in range(args.warmup):
@@ -574,6 +575,7 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=256, help="c2: clips (= captions) per GPU per step")
     ap.add_argument("--frames", type=int, default=None, help="frames per clip (default 8; c4: 16)")
     ap.add_argument("--chunk-frames", type=int, default=0)
+    ap.add_argument("--split-chunk-frames", type=int, default=0, help="frames per pass of the fp32_split_mode leg (0 = the library's 512)")
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")

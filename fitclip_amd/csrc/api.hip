@@ -366,12 +366,17 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
   if (c.precision != FC_PREC_F32) return 512;
-  if (h->split()) {  // bf16-pipe GEMMs: no whole-round planning (as in bf16 mode); the x3 MLP rows of a pass (32 w bytes each)
-    // must stay below the 4 GiB of the kernel's 32-bit row offsets
-    const long max3 = (long)(((1LL << 32) - 1) / (2LL * x3_row_elems(4L * c.vision_width)) / h->vtokens());
-    return (int)std::max(1L, std::min(512L, max3));
-  }
   const long T = h->vtokens(), w = c.vision_width, cus = device_cus();
+  if (h->split()) {
+    // bf16-pipe GEMMs: no whole-round planning, as in bf16 mode.  Measured on the 2048-frame bench step (pairs/s, share of the
+    // bf16 peak of the split GEMMs): passes of 256 frames 594 / 0.47, 384: 613 / 0.49, 512: 624 / 0.50, 600: 626, 700: 632,
+    // 768: 633-635 / 0.51, 850: 626, 886: 620; the planner's whole-round size (665 frames = 512 panels: 18 / 6 / 24 / 6 whole
+    // rounds) is the WORST of the large ones, 607 / 0.47 - with every workgroup of an XCD ending its tiles at the same moment
+    // the epilogue stores and the first DMA of the next tiles arrive in bursts.  The x3 MLP rows of a pass (32 w bytes each)
+    // must stay below the 4 GiB of the kernel's 32-bit row offsets (887 frames for ViT-B/16).
+    const long max3 = (long)(((1LL << 32) - 1) / (2LL * x3_row_elems(4L * w)) / T);
+    return (int)std::max(1L, std::min(768L, max3));
+  }
   const long max_frames = std::max(1L, (long)((1LL << 32) - 1) / (16 * w) / T);  // 32-bit operand offsets of the 4w-wide buffer
   auto rounds = [&](long frames) {  // tile rounds x K-steps of the four block GEMMs of one pass
     const long panels = (frames * T + 255) / 256;

@@ -570,12 +570,16 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
               }
             }
           }
+         }
+          // the first fragments of the next K-step, UNCONDITIONALLY (after the last step of the last tile they are never
+          // used): inside the branch above they would sit in a basic block of their own, in FRONT of this group's first MFMA
+          // (sched_group_barrier cannot order across blocks), and hipcc's lgkmcnt(0) for that MFMA's operands would wait
+          // for their whole LDS latency with the matrix pipe idle - once per K-step
           const char* nx = smem + (sidx ^ 1) * STAGE;
 #pragma unroll
           for (int j = 0; j < FN; ++j) wb[0][j] = *reinterpret_cast<const FragT*>(nx + b_base + j * 16 * ROWB + foff[0]);
 #pragma unroll
           for (int a = 0; a < 2; ++a) xp[0][a] = *reinterpret_cast<const FragT*>(nx + a_base + a * 16 * ROWB + foff[0]);
-         }
         }
         if constexpr (sizeof(T) == 4) {
           // fp32: a fragment pair is FOUR chained v_mfma_f32_16x16x4_f32 on one accumulator (40-cycle dependent latency
