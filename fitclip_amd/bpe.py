@@ -5,8 +5,9 @@
 (`aligner/encoder/clip_video_text_encoder.py:64-65`); the algorithm is the one vendored in
 `aligner/encoder/slip.py:75-164`.  Split of the work:
   * here: the text CLEANING of slip.py:63-72,138 - `html.unescape` twice, strip, `regex` white-space collapse,
-    `str.lower()` - i.e. the very library calls the reference makes (`ftfy` is not installed: texts are assumed to be
-    well-formed Unicode);
+    `str.lower()` - i.e. the very library calls the reference makes; `ftfy.fix_text` (slip.py:64) runs first when the
+    package is importable (it is not in the offline image: one warning, and texts are then assumed to be well-formed
+    Unicode - mojibake would tokenize differently from the reference; the golden ids only hold well-formed text);
   * C++: the CLIP pattern over UTF-8 (letter / number / space classes generated from the `regex` module,
     csrc/unicode_ranges.inc), byte-level merges by rank, vocabulary ids, SOT / EOT framing, truncation, padding.
 The merge list is read from a LOCAL `bpe_simple_vocab_16e6.txt.gz`-style file (no network here).
@@ -25,8 +26,28 @@ from . import _lib
 SOT, EOT = "<|startoftext|>", "<|endoftext|>"
 
 
+def _load_fix_text():
+    try:
+        import ftfy
+        return ftfy.fix_text
+    except ImportError:
+        import warnings
+        warnings.warn("ftfy is not installed: CLIP's text cleaning runs without ftfy.fix_text (slip.py:64); well-formed "
+                      "Unicode tokenizes identically, mojibake does not", RuntimeWarning, stacklevel=3)
+        return None
+
+
+_fix_text = False  # resolved on first use: False = not looked up yet, None = ftfy unavailable
+
+
 def clean_text(text: str) -> str:
-    """`whitespace_clean(basic_clean(text)).lower()` without ftfy (slip.py:63-72,138)."""
+    """`whitespace_clean(basic_clean(text)).lower()` (slip.py:63-72,138): ftfy.fix_text when available, `html.unescape`
+    twice, strip, white-space collapse, lower case."""
+    global _fix_text
+    if _fix_text is False:
+        _fix_text = _load_fix_text()
+    if _fix_text is not None:
+        text = _fix_text(text)
     return regex.sub(r"\s+", " ", html.unescape(html.unescape(text)).strip()).strip().lower()
 
 

@@ -222,11 +222,19 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
           read_w(nx, wf[par ^ 1]);
           read_a(nx, 0, af[0]);
         }
+        if constexpr (ABL == 9) {  // lab: the six products of one accumulator back to back (what a dependent MFMA costs)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+              acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][prod_w(x)][j], af[u & 1][prod_a(x)], acc[u][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int x = 0; x < 6; ++x)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
             acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][prod_w(x)][j], af[u & 1][prod_a(x)], acc[u][j], 0, 0, 0);
+        }
         // issue order inside a group: ONE MFMA, then the LDS reads of the next group, then the other MFMAs (hipcc would
         // otherwise sink the reads next to their first use, and its wait for this group's operands would cover them)
         constexpr int kReads = (u + 1 < FM) ? 3 : 3 + 3 * FN;

@@ -156,8 +156,44 @@ class ClipVideoTextEncoder(VideoTextEncoder):
         return transform
 
     def get_train_transform(self, dtype: torch.dtype) -> TYPE_TRANSFORM:
-        # Training augmentation (random resized crop + flip, reference :113-122) is outside this inference path.
-        return self.get_eval_transform(dtype)
+        """uint8 [F, H, W, C] -> `dtype` [F, C, R, R], the reference's training augmentation (:113-122): BHWC->BCHW, /255,
+        `RandomResizedCropWithRandomInterpolation(R, scale=(0.5, 1.0))` (aligner/transforms.py:56-61 over torchvision's
+        RandomResizedCrop: ONE crop box per clip - area fraction uniform in [0.5, 1], log-uniform aspect in [3/4, 4/3], ten
+        tries then the centre fallback - resized with bilinear or bicubic interpolation chosen at random, antialias off as
+        torchvision does for tensors), `RandomHorizontalFlip` (p = 0.5, the whole clip), CLIP mean/std.  Data-side
+        preprocessing of the training step, drawn from torch's global RNG (seeded by the trainer, as in the reference)."""
+        import math
+        size = self.model.visual.input_resolution
+
+        def crop_box(h: int, w: int):
+            area = h * w
+            log_lo, log_hi = math.log(3.0 / 4.0), math.log(4.0 / 3.0)
+            for _ in range(10):
+                target = area * float(torch.empty(1).uniform_(0.5, 1.0))
+                aspect = math.exp(float(torch.empty(1).uniform_(log_lo, log_hi)))
+                cw, ch = int(round(math.sqrt(target * aspect))), int(round(math.sqrt(target / aspect)))
+                if 0 < cw <= w and 0 < ch <= h:
+                    return int(torch.randint(0, h - ch + 1, (1,))), int(torch.randint(0, w - cw + 1, (1,))), ch, cw
+            ratio = w / h                                            # fallback: the largest centred box inside the bounds
+            if ratio < 3.0 / 4.0:
+                cw, ch = w, int(round(w / (3.0 / 4.0)))
+            elif ratio > 4.0 / 3.0:
+                ch, cw = h, int(round(h * (4.0 / 3.0)))
+            else:
+                cw, ch = w, h
+            return (h - ch) // 2, (w - cw) // 2, ch, cw
+
+        def transform(v: torch.Tensor) -> torch.Tensor:
+            v = v.permute(0, 3, 1, 2)
+            v = v.to(dtype) / 255 if not v.is_floating_point() else v.to(dtype)
+            top, left, ch, cw = crop_box(v.shape[-2], v.shape[-1])
+            mode = "bilinear" if int(torch.randint(0, 2, (1,))) == 0 else "bicubic"
+            v = F.interpolate(v[..., top:top + ch, left:left + cw], size=(size, size), mode=mode, align_corners=False)
+            if float(torch.rand(1)) < 0.5:
+                v = v.flip(-1)
+            return self._normalize(v)
+
+        return transform
 
     @property
     def should_pad_batch(self) -> bool:

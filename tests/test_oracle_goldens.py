@@ -248,3 +248,42 @@ def test_plugin_eval_transform_matches_the_transform_oracle(H, W):
     got = enc.get_eval_transform(torch.float32)(frames).numpy()
     want = eval_transform(frames.numpy(), 64, CLIP_MEAN, CLIP_STD)
     assert got.shape == want.shape and np.abs(got - want).max() < 2e-4  # float32 source coordinates on the torch side
+
+
+def test_train_transform_is_a_random_resized_crop_with_flip():
+    """`get_train_transform` (clip_video_text_encoder.py:113-122): output shape / dtype / normalisation, one crop box and one
+    flip decision per CLIP (all frames move together), area in [0.5, 1] of the frame, reproducible under the global seed and
+    different across seeds; a constant clip stays constant (crop + resize + flip of a constant image)."""
+    from fitclip_amd import synth
+    from fitclip_amd.clip_model import CLIP
+    from fitclip_amd.encoder import CLIP_MEAN, CLIP_STD, ClipVideoTextEncoder
+    enc = ClipVideoTextEncoder(CLIP(synth.TINY))
+    size = enc.model.visual.input_resolution
+    t = enc.get_train_transform(torch.float32)
+    g = torch.Generator().manual_seed(0)
+    clip = torch.randint(0, 256, (3, 90, 120, 3), generator=g, dtype=torch.uint8)
+    clip[1:] = clip[:1]                                        # identical frames: identical outputs iff one box per clip
+    torch.manual_seed(7)
+    a = t(clip)
+    torch.manual_seed(7)
+    b = t(clip)
+    torch.manual_seed(8)
+    c = t(clip)
+    assert a.shape == (3, 3, size, size) and a.dtype == torch.float32
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.equal(a[0], a[1]) and torch.equal(a[0], a[2])
+    flat = torch.full((2, 50, 70, 3), 128, dtype=torch.uint8)
+    out = t(flat)
+    want = (128 / 255 - torch.tensor(CLIP_MEAN)) / torch.tensor(CLIP_STD)
+    assert torch.allclose(out, want.view(1, 3, 1, 1).expand_as(out), atol=1e-5)
+    # a horizontal ramp: the output's left-to-right span tells the crop width (>= sqrt(0.5 * 3/4) of the frame) and the flip
+    ramp = torch.arange(200, dtype=torch.float32).view(1, 1, 200, 1).expand(1, 150, 200, 3).contiguous() / 199
+    spans, flips = [], 0
+    for seed in range(40):
+        torch.manual_seed(seed)
+        o = t(ramp)[0, 0] * CLIP_STD[0] + CLIP_MEAN[0]
+        span = float(o[0, -1] - o[0, 0])
+        flips += span < 0
+        spans.append(abs(span))
+    assert 0.50 <= min(spans) and max(spans) <= 1.0 + 1e-5       # narrowest box: sqrt(0.5 * 3/4) = 0.61 of the height-limited width .. 0.53 here
+    assert 8 <= flips <= 32                                     # p = 0.5 over 40 draws

@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
             {"f32 out rot8", launch_variant<EPI_BIAS_F32, 0>, 0, 9}, {"f32 out rot16", launch_variant<EPI_BIAS_F32, 0>, 0, 17},
             {"f32 out ABL2 same tile", launch_variant<EPI_BIAS_F32, 2>, 0}, {"f32 out ABL3 no-store", launch_variant<EPI_BIAS_F32, 3>, 0}, {"f32 out ABL1 no-loads", launch_variant<EPI_BIAS_F32, 1>, 0},
             {"f32 out ABL5 noload nowait", launch_variant<EPI_BIAS_F32, 5>, 0}, {"f32 out ABL6 mfma only", launch_variant<EPI_BIAS_F32, 6>, 0},
-            {"f32 out ABL7 6+no barrier", launch_variant<EPI_BIAS_F32, 7>, 0}, {"f32 out ABL8 7+no lgkm wait", launch_variant<EPI_BIAS_F32, 8>, 0}};
+            {"f32 out ABL9 6+dependent order", launch_variant<EPI_BIAS_F32, 9>, 0}, {"f32 out ABL7 6+no barrier", launch_variant<EPI_BIAS_F32, 7>, 0}, {"f32 out ABL8 7+no lgkm wait", launch_variant<EPI_BIAS_F32, 8>, 0}};
     }
     // correctness first, then interleaved timing rounds (every variant once per round; min and median over the rounds)
     std::vector<double> errs;
