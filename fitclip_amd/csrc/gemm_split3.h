@@ -90,9 +90,12 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
     const int tm = mp0 + tile / tnn, tn = tn0 + tile % tnn;
     m0 = tm * BM;
     n0 = tn * BN;
-    // neighbouring column tiles run two K-steps apart (lab sweep 0 .. 16: 0 - 2 are 3 - 5 % faster than 5 or more - a line
-    // fetched for one column tile is still in L2 when the next one asks for it); g.nblock - 1 overrides it in the lab
-    rot = (tn * (g.nblock > 0 ? g.nblock - 1 : 2)) % nk;
+    // neighbouring column tiles run ONE K-step apart: a line fetched for one column tile is still in L2 when the next tile
+    // asks for it, and no two workgroups miss on the same line at the same moment.  Lab sweep of the stride (tools/split3_lab,
+    // time and FETCH_SIZE per launch at 512 frames): 0 - 2 are 3 - 5 % faster than 5 or more; QKV fetches 3.8 / 3.5 / 4.0 / 5.3 GB
+    // with stride 0 / 1 / 2 / 3, c_fc (with its N split) 3.6 GB with 1 against 4.2 with 2.  Lockstep groups of 2 - 4 column
+    // tiles (g.P, lab only) change nothing.  g.nblock - 1 overrides the stride in the lab.
+    rot = ((tn / (g.P > 0 ? g.P : 1)) * (g.nblock > 0 ? g.nblock - 1 : 1)) % nk;
 #pragma unroll
     for (int i = 0; i < LPA; ++i) {
       const int c6 = (wave + i * NW) * 64 + lane, row = c6 / 6, c = c6 - row * 6;

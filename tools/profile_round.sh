@@ -1,14 +1,14 @@
 #!/bin/bash
 # Reproduces the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun, from the repo root):
-#   tools/profile_round.sh r02 fp32        # the headline precision
-#   tools/profile_round.sh r02 bf16        # the secondary mode
-#   tools/profile_round.sh r02 fp32x6      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on)
+#   tools/profile_round.sh r03 fp32        # the headline precision
+#   tools/profile_round.sh r03 bf16        # the secondary mode
+#   tools/profile_round.sh r03 fp32x6      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on)
 # 1. kernel trace + stats of the bench command for that precision (CPU leg and the other precision off);
 # 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) and 4. an SQ pass for the dominant kernel (c_fc + QuickGELU GEMM).
 # Raw output goes to gpurun_out/prof_*; summaries to profiles/ AND gpurun_out/profiles_<tag>/ (the latter travels back).
 # The program stays directly after `--` (no env / bash -c hop: the profiler has already initialised the GPU).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 prec=${2:-fp32}
 repo=$(pwd)
 out=$repo/gpurun_out
@@ -34,12 +34,13 @@ elif [ "$prec" = bf16 ]; then
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi0E|365|1e9|$rows|768|3072|bias"
 else
-  # fp32x6 = the split-fp32 leg of the fp32 bench run (passes of 512 frames; three-plane operands, six bf16 products per
-  # fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation (epilogue 7); c_proj
-  # shares epilogue 6 with QKV / out_proj and is the only one of them above 1.95 ms (QKV 1.7, out_proj 0.6)
-  steps=3; chunk=512; rows=$((chunk * 197))
-  spec_fc="gemm_split3_kernel<7,|1900|1e9|$rows|3072|4608|bias_quickgelu_x3_out"
-  spec_proj="gemm_split3_kernel<6,|1950|1e9|$rows|768|18432|bias_f32_out"
+  # fp32x6 = the split-fp32 leg of the fp32 bench run (the 2048 frames of a step run as 768 + 768 + 512; three-plane operands,
+  # six bf16 products per fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation
+  # (epilogue 7; 3.4 ms at 768 frames, 2.3 at 512); c_proj shares epilogue 6 with QKV / out_proj and is the only one of them
+  # above 2.9 ms (at 768 frames: c_proj 3.2, QKV 2.55, out_proj 0.85)
+  steps=3; chunk=768; rows=$((chunk * 197))
+  spec_fc="gemm_split3_kernel<7,|3000|1e9|$rows|3072|4608|bias_quickgelu_x3_out"
+  spec_proj="gemm_split3_kernel<6,|2900|1e9|$rows|768|18432|bias_f32_out"
 fi
 if [ "$prec" = fp32x6 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"

@@ -109,20 +109,23 @@ int main(int argc, char** argv) {
     GemmArgs a{};
     a.A = A3; a.W = W3; a.bias = bias; a.C = C; a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K; a.lda = (int)lda; a.ldw = (int)lda; a.ldc = (int)ldc;
-    struct V { const char* name; void (*fn)(const GemmArgs&, hipStream_t); int nsplit; int nblock = 0; };
+    struct V { const char* name; void (*fn)(const GemmArgs&, hipStream_t); int nsplit; int nblock = 0; int P = 0; };
     std::vector<V> vs;
     if (sh.x3) {
       vs = {{"x3 gelu", launch_variant<EPI_GELU_X3, 0>, 0}, {"x3 gelu nsplit4", launch_variant<EPI_GELU_X3, 0>, 4},
             {"x3 gelu rot0", launch_variant<EPI_GELU_X3, 0>, 0, 1}, {"x3 gelu rot1", launch_variant<EPI_GELU_X3, 0>, 0, 2},
             {"x3 gelu rot2", launch_variant<EPI_GELU_X3, 0>, 0, 3}, {"x3 gelu rot3", launch_variant<EPI_GELU_X3, 0>, 0, 4},
             {"x3 gelu rot1 nsplit4", launch_variant<EPI_GELU_X3, 0>, 4, 2}, {"x3 gelu rot2 nsplit4", launch_variant<EPI_GELU_X3, 0>, 4, 3},
+            {"x3 gelu rot1 grp2", launch_variant<EPI_GELU_X3, 0>, 0, 2, 2}, {"x3 gelu rot1 grp3", launch_variant<EPI_GELU_X3, 0>, 0, 2, 3},
+            {"x3 gelu rot2 grp3", launch_variant<EPI_GELU_X3, 0>, 0, 3, 3}, {"x3 gelu rot1 grp4", launch_variant<EPI_GELU_X3, 0>, 0, 2, 4},
+            {"x3 gelu rot2 grp4 nsplit4", launch_variant<EPI_GELU_X3, 0>, 4, 3, 4},
             {"x3 gelu ABL2 same tile", launch_variant<EPI_GELU_X3, 2>, 0}, {"x3 gelu ABL3 no-store", launch_variant<EPI_GELU_X3, 3>, 0}, {"x3 gelu ABL1 no-loads", launch_variant<EPI_GELU_X3, 1>, 0},
             {"x3 gelu ABL5 noload nowait", launch_variant<EPI_GELU_X3, 5>, 0}, {"x3 gelu ABL6 mfma only", launch_variant<EPI_GELU_X3, 6>, 0}};
     } else {
       vs = {{"f32 out", launch_variant<EPI_BIAS_F32, 0>, 0}, {"f32 out nsplit4", launch_variant<EPI_BIAS_F32, 0>, 4},
             {"f32 out rot0", launch_variant<EPI_BIAS_F32, 0>, 0, 1}, {"f32 out rot1", launch_variant<EPI_BIAS_F32, 0>, 0, 2},
             {"f32 out rot2", launch_variant<EPI_BIAS_F32, 0>, 0, 3}, {"f32 out rot3", launch_variant<EPI_BIAS_F32, 0>, 0, 4},
-            {"f32 out rot8", launch_variant<EPI_BIAS_F32, 0>, 0, 9}, {"f32 out rot16", launch_variant<EPI_BIAS_F32, 0>, 0, 17},
+            {"f32 out rot1 grp3", launch_variant<EPI_BIAS_F32, 0>, 0, 2, 3}, {"f32 out rot2 grp3", launch_variant<EPI_BIAS_F32, 0>, 0, 3, 3},
             {"f32 out ABL2 same tile", launch_variant<EPI_BIAS_F32, 2>, 0}, {"f32 out ABL3 no-store", launch_variant<EPI_BIAS_F32, 3>, 0}, {"f32 out ABL1 no-loads", launch_variant<EPI_BIAS_F32, 1>, 0},
             {"f32 out ABL5 noload nowait", launch_variant<EPI_BIAS_F32, 5>, 0}, {"f32 out ABL6 mfma only", launch_variant<EPI_BIAS_F32, 6>, 0},
             {"f32 out ABL9 6+dependent order", launch_variant<EPI_BIAS_F32, 9>, 0}, {"f32 out ABL7 6+no barrier", launch_variant<EPI_BIAS_F32, 7>, 0}, {"f32 out ABL8 7+no lgkm wait", launch_variant<EPI_BIAS_F32, 8>, 0}};
@@ -133,6 +136,7 @@ int main(int argc, char** argv) {
       GemmArgs b = a;
       b.nsplit = v.nsplit;
       b.nblock = v.nblock;
+      b.P = v.P;
       HIP_OK(hipMemsetAsync(C, 0, cbytes, st));
       v.fn(b, st);
       HIP_OK(hipGetLastError());
@@ -151,6 +155,7 @@ int main(int argc, char** argv) {
         GemmArgs b = a;
         b.nsplit = vs[vi].nsplit;
         b.nblock = vs[vi].nblock;
+        b.P = vs[vi].P;
         vs[vi].fn(b, st);
         HIP_OK(hipEventRecord(e0, st));
         for (int i = 0; i < reps; ++i) vs[vi].fn(b, st);
