@@ -19,7 +19,10 @@
 // and on the fragment reads (same involution).  The DMA of K-step k + 3 is issued at the hand-over of step k, so every
 // operand line has two whole K-steps (~5 us) to arrive: measured in tools/split3_lab, the K loop's loss against its
 // no-load ablation is DMA latency (L2 / HBM), not DMA issue - issuing the pieces LATER (behind MFMA groups of the next step, as
-// the bf16 kernel's piece schedules do) made every shape slower, an XCD-local N range (nsplit) faster.  The three stages
+// the bf16 kernel's piece schedules do) made every shape slower with TWO stages, an XCD-local N range (nsplit) faster; with the
+// third stage the same spreading (SPREAD = 1: two pieces behind each of the first three MFMA groups of step k + 1) gains
+// 4 - 8 %: the bursts of 48 pieces per CU filled the L1's pending-miss queue (TCP_PENDING_STALL_CYCLES 24 % of the launch)
+// and a wave stuck on a DMA instruction issues no MFMAs.  The three stages
 // leave no LDS for output patches, so the epilogue borrows the stage the tile's last K-step has just released (the DMA that
 // would refill it - K-step 2 of the next tile - waits for the barrier that ends the epilogue).
 // Hand-over in front of the last MFMA group, counted vmcnt behind the epilogue stores, LDS-transposed full-width stores: the
@@ -39,7 +42,10 @@ constexpr int prod_w(int x) { return x == 1 || x == 3 ? 1 : (x == 4 ? 2 : 0); }
 // ABL (tools/split3_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 2 = every workgroup stages the operand
 // rows of tile (0, 0) (all loads hit L2); 3 = no epilogue; 5 = no loads and no
 // vmcnt waits in the K loop (the epilogue's stores drain unobserved); 6 = no loads, no waits, no epilogue (MFMA + LDS reads only)
-template <int EPI, int ABL = 0>
+// SPREAD: 0 = the six LDS-DMA pieces a wave contributes to K-step k + 3 are issued in one burst at the hand-over of step k;
+// 1 = they are issued during step k + 1, two behind each of its first three MFMA groups (the stage is free since the
+// hand-over of step k; they still have more than a K-step to land).
+template <int EPI, int ABL = 0, int SPREAD = 0>
 __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 x 64 per wave
@@ -124,6 +130,20 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[i] + (unsigned)kt * X3_GROUP_BYTES)),
           (__attribute__((address_space(3))) void*)(dst + BM * ROW3 + i * NW * 1024), 16, 0, 0);
   };
+  auto stage_piece = [&](int stage_off, int kt, auto IDX) {  // piece IDX (0..2 activations, 3..5 weights) of stage_load
+    constexpr int idx = decltype(IDX)::value;
+    kt += rot;
+    if (kt >= nk) kt -= nk;
+    char* dst = smem + stage_off + wave * 1024;
+    if constexpr (idx < LPA)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[idx] + (unsigned)kt * X3_GROUP_BYTES)),
+          (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[idx - LPA] + (unsigned)kt * X3_GROUP_BYTES)),
+          (__attribute__((address_space(3))) void*)(dst + BM * ROW3 + (idx - LPA) * NW * 1024), 16, 0, 0);
+  };
   auto bias_load = [&](int buf, int n0) {  // BN floats -> LDS by one LDS-DMA of wave 0 (older than that tile's first K-step)
     if (wave == 0) {
       const float* p = g.bias + min(n0 + lane * 4, g.N - 4);
@@ -206,16 +226,24 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
           }
           if constexpr (ABL != 7 && ABL != 8) block_barrier();  // 7 / 8: no hand-over barrier (lab: what the barrier costs)
           if (ABL != 1 && ABL < 5) {
-            if (kt + 3 < nk) {
-              stage_load(s_cur, kt + 3);
-            } else if (has_next) {
-              if (kt + 3 == nk) {
+            if constexpr (SPREAD == 0) {
+              if (kt + 3 < nk) {
+                stage_load(s_cur, kt + 3);
+              } else if (has_next) {
+                if (kt + 3 == nk) {
+                  tile_sources(tnext, m0, n0);
+                  bias_load((it + 1) & 1, n0);
+                  stage_load(s_cur, 0);
+                } else if (kt + 2 == nk) {
+                  stage_load(s_cur, 1);
+                }  // kt + 1 == nk: this stage is the epilogue's patch area; K-step 2 of the next tile follows the epilogue
+              }
+            } else {
+              // the pieces of K-step kt + 3 follow during step kt + 1; only the next tile's staging offsets are due here
+              if (has_next && kt + 3 == nk) {
                 tile_sources(tnext, m0, n0);
                 bias_load((it + 1) & 1, n0);
-                stage_load(s_cur, 0);
-              } else if (kt + 2 == nk) {
-                stage_load(s_cur, 1);
-              }  // kt + 1 == nk: this stage is the epilogue's patch area; K-step 2 of the next tile follows the epilogue
+              }
             }
           }
           // the first fragments of the next K-step, UNCONDITIONALLY (after the last step of the last tile they are never
@@ -225,6 +253,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
           read_w(nx, wf[par ^ 1]);
           read_a(nx, 0, af[0]);
         }
+        constexpr bool kMid = SPREAD == 2 && ABL != 1 && ABL < 5 && u + 1 < FM;  // a piece in the MIDDLE of the group too
         if constexpr (ABL == 9) {  // lab: the six products of one accumulator back to back (what a dependent MFMA costs)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
@@ -233,17 +262,45 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
               acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][prod_w(x)][j], af[u & 1][prod_a(x)], acc[u][j], 0, 0, 0);
         } else {
 #pragma unroll
-        for (int x = 0; x < 6; ++x)
+          for (int x = 0; x < 6; ++x) {
+            if constexpr (kMid) {
+              if (x == 3 && kt >= 1 && (kt + 2 < nk || has_next))
+                stage_piece(s_aft, kt + 2 < nk ? kt + 2 : kt + 2 - nk, std::integral_constant<int, 2 * u>{});
+            }
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][prod_w(x)][j], af[u & 1][prod_a(x)], acc[u][j], 0, 0, 0);
+            for (int j = 0; j < FN; ++j)
+              acc[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][prod_w(x)][j], af[u & 1][prod_a(x)], acc[u][j], 0, 0, 0);
+          }
         }
         // issue order inside a group: ONE MFMA, then the LDS reads of the next group, then the other MFMAs (hipcc would
         // otherwise sink the reads next to their first use, and its wait for this group's operands would cover them)
         constexpr int kReads = (u + 1 < FM) ? 3 : 3 + 3 * FN;
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * FN - 1, 0);
+        if constexpr (kMid) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * FN - 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * FN, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 6 * FN - 1, 0);
+        }
+        if constexpr (SPREAD >= 1 && ABL != 1 && ABL < 5 && u + 1 < FM) {
+          // pieces of K-step kt + 2 (of this tile, or K-step 0 / 1 of the next one) into the stage released at the
+          // hand-over of step kt - 1; K-step 2 of a tile always arrives whole (prologue / behind the epilogue)
+          if (kt >= 1 && (kt + 2 < nk || has_next)) {
+            const int lk = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+            if constexpr (SPREAD == 1) {         // two behind each of groups 0, 1, 2
+              stage_piece(s_aft, lk, std::integral_constant<int, 2 * u>{});
+              stage_piece(s_aft, lk, std::integral_constant<int, 2 * u + 1>{});
+            } else if constexpr (SPREAD == 2) {  // one in the middle of the group (above), one behind it
+              stage_piece(s_aft, lk, std::integral_constant<int, 2 * u + 1>{});
+            } else if constexpr (u < 2) {        // 3: three behind each of groups 0, 1
+              stage_piece(s_aft, lk, std::integral_constant<int, 3 * u>{});
+              stage_piece(s_aft, lk, std::integral_constant<int, 3 * u + 1>{});
+              stage_piece(s_aft, lk, std::integral_constant<int, 3 * u + 2>{});
+            }
+          }
+        }
       });
       const int released = s_cur;
       s_cur = s_nxt;

@@ -22,7 +22,10 @@ int cu_count() {
 template <int EPI>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = 3 * 512 * 96 + 2048;  // three stages (the epilogue borrows the released one) + two bias slices
-  auto kern = gemm_split3_kernel<EPI>;
+  // SPREAD = 1: the LDS-DMA pieces of a K-step are issued two at a time behind MFMA groups of the step before (lab: 4 - 8 % over
+  // one burst of six per wave at the hand-over - with the bursts the L1's pending-miss queue fills, the TA stalls, and a wave
+  // stuck on a DMA instruction issues no MFMAs: TCP_PENDING_STALL_CYCLES 24 % of the launch, tools/split3_lab + rocprofv3)
+  auto kern = gemm_split3_kernel<EPI, 0, 1>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split3: cannot raise dynamic LDS to %d bytes", lds);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);

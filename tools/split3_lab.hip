@@ -66,10 +66,10 @@ __global__ void check(const float* A, const float* W, const float* bias, const v
   out[2 * s + 1] = got;
 }
 
-template <int EPI, int ABL>
+template <int EPI, int ABL, int SPREAD = 0>
 void launch_variant(const GemmArgs& a, hipStream_t st) {
   constexpr int lds = 3 * 512 * 96 + 2048;
-  auto kern = gemm_split3_kernel<EPI, ABL>;
+  auto kern = gemm_split3_kernel<EPI, ABL, SPREAD>;
   static bool configured = false;
   if (!configured) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -113,6 +113,9 @@ int main(int argc, char** argv) {
     std::vector<V> vs;
     if (sh.x3) {
       vs = {{"x3 gelu", launch_variant<EPI_GELU_X3, 0>, 0}, {"x3 gelu nsplit4", launch_variant<EPI_GELU_X3, 0>, 4},
+            {"x3 gelu spread", launch_variant<EPI_GELU_X3, 0, 1>, 0}, {"x3 gelu spread nsplit4", launch_variant<EPI_GELU_X3, 0, 1>, 4},
+            {"x3 gelu spread ABL2", launch_variant<EPI_GELU_X3, 2, 1>, 0},
+            {"x3 gelu spread2 nsplit4", launch_variant<EPI_GELU_X3, 0, 2>, 4}, {"x3 gelu spread3 nsplit4", launch_variant<EPI_GELU_X3, 0, 3>, 4},
             {"x3 gelu rot0", launch_variant<EPI_GELU_X3, 0>, 0, 1}, {"x3 gelu rot1", launch_variant<EPI_GELU_X3, 0>, 0, 2},
             {"x3 gelu rot2", launch_variant<EPI_GELU_X3, 0>, 0, 3}, {"x3 gelu rot3", launch_variant<EPI_GELU_X3, 0>, 0, 4},
             {"x3 gelu rot1 nsplit4", launch_variant<EPI_GELU_X3, 0>, 4, 2}, {"x3 gelu rot2 nsplit4", launch_variant<EPI_GELU_X3, 0>, 4, 3},
@@ -123,6 +126,8 @@ int main(int argc, char** argv) {
             {"x3 gelu ABL5 noload nowait", launch_variant<EPI_GELU_X3, 5>, 0}, {"x3 gelu ABL6 mfma only", launch_variant<EPI_GELU_X3, 6>, 0}};
     } else {
       vs = {{"f32 out", launch_variant<EPI_BIAS_F32, 0>, 0}, {"f32 out nsplit4", launch_variant<EPI_BIAS_F32, 0>, 4},
+            {"f32 out spread", launch_variant<EPI_BIAS_F32, 0, 1>, 0}, {"f32 out spread ABL2", launch_variant<EPI_BIAS_F32, 2, 1>, 0},
+            {"f32 out spread2 (mid)", launch_variant<EPI_BIAS_F32, 0, 2>, 0}, {"f32 out spread3 (3+3)", launch_variant<EPI_BIAS_F32, 0, 3>, 0},
             {"f32 out rot0", launch_variant<EPI_BIAS_F32, 0>, 0, 1}, {"f32 out rot1", launch_variant<EPI_BIAS_F32, 0>, 0, 2},
             {"f32 out rot2", launch_variant<EPI_BIAS_F32, 0>, 0, 3}, {"f32 out rot3", launch_variant<EPI_BIAS_F32, 0>, 0, 4},
             {"f32 out rot1 grp3", launch_variant<EPI_BIAS_F32, 0>, 0, 2, 3}, {"f32 out rot2 grp3", launch_variant<EPI_BIAS_F32, 0>, 0, 3, 3},
