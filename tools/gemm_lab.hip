@@ -5,6 +5,7 @@
 // then times `reps` back-to-back launches with hipEvents on random (never zero-filled) operands.
 #include "gemm_kernel.h"
 #include "gemm_deep_lab.h"
+#include "gemm_ring_lab.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -104,6 +105,19 @@ template <int EPI, int ABL>
 void launch_deep(const GemmArgs& a, hipStream_t st) {
   constexpr int lds = 4 * 512 * 64 + 8 * 2048 + 2048;
   auto kern = gemm_deep_kernel<EPI, ABL>;
+  static bool configured = false;
+  if (!configured) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
+}
+
+template <int EPI, int ABL>
+void launch_ring(const GemmArgs& a, hipStream_t st) {
+  constexpr int lds = 4 * 512 * 64 + 2048;
+  auto kern = gemm_ring_kernel<EPI, ABL>;
   static bool configured = false;
   if (!configured) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
