@@ -201,3 +201,24 @@ def test_split_mode_is_as_close_to_float64_as_fp32_arithmetic_itself(vitb16_stat
     print("max |embedding - float64 truth|:", err)
     assert err["fp32x6"] < 1e-6 and err["fp32"] < 1e-6
     assert err["fp32x6"] <= 2.0 * max(err["oracle fp32"], err["fp32"]) + 5e-8, err
+
+
+def test_gemm_split3_race_screen():
+    """The three-plane GEMM orders its LDS-DMA against fragment reads with counted vmcnt waits and one barrier per K-step
+    (three-stage ring, pieces spread over MFMA groups, the epilogue borrowing the released stage).  A misplaced wait would show
+    as rare wrong tiles, not as a failure of a single run: 40 launches of a multi-round shape (5 tiles per workgroup, ragged
+    last panel, both epilogues) must reproduce the first result bitwise, with another GEMM's traffic in between."""
+    g = torch.Generator(device=DEV).manual_seed(7)
+    M, N, K = 256 * 105 + 77, 3072, 768
+    a3 = ops.split3(torch.randn(M, K, device=DEV, generator=g))
+    w3 = ops.split3(torch.randn(N, K, device=DEV, generator=g) / K ** 0.5)
+    bias = torch.randn(N, device=DEV, generator=g)
+    other_a = ops.split3(torch.randn(30000, 3072, device=DEV, generator=g))
+    other_w = ops.split3(torch.randn(768, 3072, device=DEV, generator=g) / 3072 ** 0.5)
+    other_b = torch.zeros(768, device=DEV)
+    first = {epi: ops.gemm_split3(a3, w3, bias, epi) for epi in (ops.EPI_BIAS_F32, ops.EPI_GELU_X3)}
+    first_other = ops.gemm_split3(other_a, other_w, other_b)
+    for i in range(20):
+        for epi in (ops.EPI_BIAS_F32, ops.EPI_GELU_X3):
+            assert torch.equal(ops.gemm_split3(a3, w3, bias, epi), first[epi]), (i, epi)
+        assert torch.equal(ops.gemm_split3(other_a, other_w, other_b), first_other), i

@@ -115,6 +115,8 @@ int main(int argc, char** argv) {
       vs = {{"x3 gelu", launch_variant<EPI_GELU_X3, 0>, 0}, {"x3 gelu nsplit4", launch_variant<EPI_GELU_X3, 0>, 4},
             {"x3 gelu spread", launch_variant<EPI_GELU_X3, 0, 1>, 0}, {"x3 gelu spread nsplit4", launch_variant<EPI_GELU_X3, 0, 1>, 4},
             {"x3 gelu spread ABL2", launch_variant<EPI_GELU_X3, 2, 1>, 0},
+            {"x3 gelu spread nsplit2", launch_variant<EPI_GELU_X3, 0, 1>, 2}, {"x3 gelu spread nsplit2 rot1", launch_variant<EPI_GELU_X3, 0, 1>, 2, 2},
+            {"x3 gelu spread nsplit4 rot1", launch_variant<EPI_GELU_X3, 0, 1>, 4, 2},
             {"x3 gelu spread2 nsplit4", launch_variant<EPI_GELU_X3, 0, 2>, 4}, {"x3 gelu spread3 nsplit4", launch_variant<EPI_GELU_X3, 0, 3>, 4},
             {"x3 gelu rot0", launch_variant<EPI_GELU_X3, 0>, 0, 1}, {"x3 gelu rot1", launch_variant<EPI_GELU_X3, 0>, 0, 2},
             {"x3 gelu rot2", launch_variant<EPI_GELU_X3, 0>, 0, 3}, {"x3 gelu rot3", launch_variant<EPI_GELU_X3, 0>, 0, 4},
