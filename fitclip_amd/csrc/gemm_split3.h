@@ -55,14 +55,13 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   constexpr int LPA = BM * 6 / 64 / NW, LPB = BN * 6 / 64 / NW, LPW = LPA + LPB;  // LDS-DMA pieces per wave and stage: 3 + 3
   constexpr int OFF_BIAS = 3 * STAGE;              // 2 x 1 KiB behind the three stages
   constexpr int PATCH = STAGE / NW;                // 6 KiB of the released stage per wave during the epilogue
-  constexpr int ROWX = 112;                        // x3 patch row stride: 96 bytes of planes + 16 (2-way instead of 4-way write conflicts)
   constexpr bool kOutX3 = EPI == EPI_GELU_X3;
   constexpr int NST = kOutX3 ? FM * FN * 2 * 4 : FM * FN * 4;  // store instructions per wave and interior tile: 64 / 32
   // the counted wait behind the epilogue stores needs 2 LPW + NST to fit the 6-bit vmcnt; the x3 epilogue (whole 128-byte lines:
   // 64 stores) waits for its stores at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;
   static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X3, "epilogue");
-  static_assert(32 * ROWX <= PATCH && 32 * 128 <= PATCH, "output patch");
+  static_assert(32 * 128 <= PATCH, "output patch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -351,9 +350,20 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
         }
       } else {
         // x3 outputs (the next GEMM's activation operand): exact QuickGELU, then the three planes of 32 rows x 16 columns go
-        // through the wave's patch as [row][p1 | p2 | p3][32 bytes] and leave as WHOLE 128-byte lines, 8 rows per store
-        // instruction: chunk x = 8 row + c lands at byte 16 c of that row's line, c = 6, 7 are zeros (a line written only in
-        // part costs a read-modify-write at the memory side)
+        // through the wave's patch - 32 rows x 128 bytes [p1 | p2 | p3 | zeros], 16-byte chunk c of row r at chunk c ^ (r & 7) -
+        // and leave as WHOLE 128-byte lines, 8 rows per store instruction (a line written only in part costs a
+        // read-modify-write at the memory side).  The zero quarter of the patch is written once per tile.
+        {
+          const int zrow = lane >> 1, zc = 6 + (lane & 1);
+          *reinterpret_cast<f32x4*>(stg + zrow * 128 + ((zc ^ (zrow & 7)) << 4)) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int rrow = lane >> 3, rch = lane & 7;
+        const size_t ldc_b = (size_t)g.ldc * 2;
+        char* cbase = reinterpret_cast<char*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * ldc_b + rch * 16;
+        const int rd_off[4] = {(rrow) * 128 + ((rch ^ (rrow & 7)) << 4), (8 + rrow) * 128 + ((rch ^ (rrow & 7)) << 4),
+                               (16 + rrow) * 128 + ((rch ^ (rrow & 7)) << 4), (24 + rrow) * 128 + ((rch ^ (rrow & 7)) << 4)};
+        char* wr = stg + r * 128 + h * 8;
+        const int wx = r & 7;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -368,22 +378,18 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
                 bf16x4 p1, p2, p3;
                 split3(v, p1, p2, p3);
-                char* w0 = stg + r * ROWX + gh * 16 + h * 8;
-                *reinterpret_cast<bf16x4*>(w0) = p1;
-                *reinterpret_cast<bf16x4*>(w0 + 32) = p2;
-                *reinterpret_cast<bf16x4*>(w0 + 64) = p3;
+                *reinterpret_cast<bf16x4*>(wr + (((0 + gh) ^ wx) << 4)) = p1;
+                *reinterpret_cast<bf16x4*>(wr + (((2 + gh) ^ wx) << 4)) = p2;
+                *reinterpret_cast<bf16x4*>(wr + (((4 + gh) ^ wx) << 4)) = p3;
               }
-              const int mo0 = cm0 + wm * TM + i * 32;
-              const int group = (cn0 + wn * TN + j * 32 + cg * 16) / X3_GROUP;
+              const int mo0 = cm0 + wm * TM + i * 32;                                      // wave-uniform
+              const int group = (cn0 + wn * TN + j * 32 + cg * 16) / X3_GROUP;             // wave-uniform
+              char* tile_base = cbase + (size_t)(i * 32) * ldc_b + (size_t)group * X3_GROUP_BYTES;
 #pragma unroll
               for (int s = 0; s < 4; ++s) {
-                const int row = s * 8 + (lane >> 3), c = lane & 7;
-                bf16x8 val = {};
-                if (c < 6) val = *reinterpret_cast<const bf16x8*>(stg + row * ROWX + c * 16);
-                if (interior || (mo0 + row < g.M && group * X3_GROUP < g.N)) {
-                  char* dst = reinterpret_cast<char*>(g.C) + ((size_t)(mo0 + row) * g.ldc) * 2 + (size_t)group * X3_GROUP_BYTES + c * 16;
-                  __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(dst));
-                }
+                const bf16x8 val = *reinterpret_cast<const bf16x8*>(stg + rd_off[s]);
+                if (interior || (mo0 + s * 8 + rrow < g.M && group * X3_GROUP < g.N))
+                  __builtin_nontemporal_store(val, reinterpret_cast<bf16x8*>(tile_base + (size_t)(s * 8) * ldc_b));
               }
             }
           }

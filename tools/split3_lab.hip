@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
     GemmArgs a{};
     a.A = A3; a.W = W3; a.bias = bias; a.C = C; a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K; a.lda = (int)lda; a.ldw = (int)lda; a.ldc = (int)ldc;
-    struct V { const char* name; void (*fn)(const GemmArgs&, hipStream_t); int nsplit; int nblock = 0; int P = 0; };
+    struct V { const char* name; void (*fn)(const GemmArgs&, hipStream_t); int nsplit; int nblock = 0; int P = 0; int gR = 0; };
     std::vector<V> vs;
     if (sh.x3) {
       vs = {{"x3 gelu", launch_variant<EPI_GELU_X3, 0>, 0}, {"x3 gelu nsplit4", launch_variant<EPI_GELU_X3, 0>, 4},
@@ -144,6 +144,7 @@ int main(int argc, char** argv) {
       b.nsplit = v.nsplit;
       b.nblock = v.nblock;
       b.P = v.P;
+      b.gR = v.gR;
       HIP_OK(hipMemsetAsync(C, 0, cbytes, st));
       v.fn(b, st);
       HIP_OK(hipGetLastError());
@@ -163,6 +164,7 @@ int main(int argc, char** argv) {
         b.nsplit = vs[vi].nsplit;
         b.nblock = vs[vi].nblock;
         b.P = vs[vi].P;
+        b.gR = vs[vi].gR;
         vs[vi].fn(b, st);
         HIP_OK(hipEventRecord(e0, st));
         for (int i = 0; i < reps; ++i) vs[vi].fn(b, st);
