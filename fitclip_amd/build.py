@@ -13,7 +13,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 REPO = CSRC.parent.parent
 LIB = CSRC / "libfitclip_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm_split3.hip", "attention.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_split3.hip", "attention.hip", "attention_split.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
            "train.hip", "bpe.cpp"]
 HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "gemm_split3.h", CSRC / "handle.h", CSRC / "unicode_ranges.inc",
            REPO / "include" / "fitclip_hip.h"]

@@ -325,7 +325,10 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
     FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.in_w3, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
-      if (attention_x3_supported(S, 0)) {
+      static const bool f32_attention = getenv("FITCLIP_SPLIT_ATTN_F32") != nullptr;  // A/B switch: the fp32-MFMA kernel
+      if (attention_split_supported(S, 0) && !f32_attention) {
+        FC_TRY(launch_attention_split(s.big, s.xn, n_seq, S, heads, st));
+      } else if (attention_x3_supported(S, 0)) {
         FC_TRY(launch_attention_x3(s.big, s.xn, n_seq, S, heads, st));
       } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
         FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
@@ -697,6 +700,10 @@ int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, i
   if (precision == KIND_X3) {  // fp32 in, x3 rows out (the sequence lengths the streaming-block kernel serves)
     if (causal) return fail(FC_EINVAL, "fc_attention: the three-plane output is not available for causal attention");
     return launch_attention_x3(qkv, out, n_seq, S, heads, st);
+  }
+  if (precision == ATTN_SPLIT) {  // fp32 in, x3 rows out, six bf16 products per fp32 product (193..208 tokens)
+    if (causal) return fail(FC_EINVAL, "fc_attention: split-fp32 attention is not available for causal attention");
+    return launch_attention_split(qkv, out, n_seq, S, heads, st);
   }
   return launch_attention(precision, qkv, out, n_seq, S, heads, causal, st);
 }

@@ -161,20 +161,6 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(const bf16* __restrict__
   }
 }
 
-// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} on v_permlane32_swap / v_permlane16_swap (no LDS round trip)
-__device__ __forceinline__ float max_over_lane_groups(float x) {
-  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-__device__ __forceinline__ float sum_over_lane_groups(float x) {
-  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 kernel, second generation (what the first profile asked for: the v1 kernel above spent its time in exposed
 // staging latency, 2-byte output stores and an unbalanced 13-tiles-over-4-waves split, not in MFMAs):
@@ -659,14 +645,6 @@ __global__ void __launch_bounds__(NW * 64) attn_f32_mfma_kernel(const float* __r
 // ABL (tools/attn_lab_f32.hip only): 1 = no exponentials, 2 = V operand not read from LDS, 3 = K operand not read from
 // LDS, 4 = no staging, 5 = no P.V products, 6 = no S products.  (Per-wave s_setprio to break the phase lock of the
 // waves of a SIMD: measured +1 %, not kept.)
-// exp(x) for FINITE x <= 0 (no masked keys in the tile): exp_neg_f32 (common.h) without its clamp and select
-__device__ __forceinline__ float exp_neg_finite_f32(float x) {
-  constexpr float kHi = 1.4426950216293335f, kLo = 1.925963033500011e-08f;
-  const float t = x * kHi;
-  const float r = __builtin_fmaf(x, kLo, __builtin_fmaf(x, kHi, -t));
-  const float e = __builtin_amdgcn_exp2f(t);
-  return __builtin_fmaf(e, r * 0.6931471805599453f, e);
-}
 // X3: `out` is written as x3 rows [rows, 4 D bf16 positions] of the fp32 result (split-fp32 mode: out_proj's A operand).
 template <int NW, int ABL = 0, bool X3 = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4)))  // <= 128 VGPRs: two workgroups per CU

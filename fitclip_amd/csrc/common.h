@@ -108,6 +108,11 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
 // fp32 attention whose output is written as x3 rows [n_seq * S, 4 * heads * 64 bf16] (out_proj's operand in split-fp32 mode)
 bool attention_x3_supported(int S, int causal);
 int launch_attention_x3(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream);
+// split-fp32 attention (attention_split.hip): fp32 qkv in, x3 rows out, both products as six bf16 products on the bf16
+// matrix cores; non-causal, 193..208 tokens (the ViT's 197)
+constexpr int ATTN_SPLIT = 4;  // `precision` argument of fc_attention
+bool attention_split_supported(int S, int causal);
+int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream);
 
 // --------------------------------------------------------------------------------------------- row ops
 // y[i] = LN(x[row(i)]) * gamma + beta.  row(i) = gather ? gather[i] : i; x row r at x + r * x_stride.
@@ -199,6 +204,30 @@ __device__ __forceinline__ float exp_neg_f32(float x) {
   e = __builtin_fmaf(e, r * 0.6931471805599453f, e);
   return x > -80.f ? e : 0.f;
 }
+
+// exp(x) for FINITE x <= 0 (no masked keys in the tile): exp_neg_f32 (common.h) without its clamp and select
+__device__ __forceinline__ float exp_neg_finite_f32(float x) {
+  constexpr float kHi = 1.4426950216293335f, kLo = 1.925963033500011e-08f;
+  const float t = x * kHi;
+  const float r = __builtin_fmaf(x, kLo, __builtin_fmaf(x, kHi, -t));
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.6931471805599453f, e);
+}
+
+// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} on v_permlane32_swap / v_permlane16_swap (no LDS round trip)
+__device__ __forceinline__ float max_over_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_over_lane_groups(float x) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 
 // QuickGELU in fp32 (slip.py:359-361): x * sigmoid(1.702 x) = x / (1 + 2^t), t = -(1.702 log2 e) x.
 // v_exp_f32 / v_rcp_f32 are 1-ulp instructions; what would cost accuracy is the rounding of the product t (|t| up to ~40),

@@ -11,7 +11,9 @@ from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X3, EPI_PATCH_
                    PREC_BF16, PREC_F32)
 
 _KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
-KIND_X3 = 3  # element-kind argument of the row kernels / attention: x3 rows out (three bf16 planes, csrc/common.h)
+KIND_X3 = 3
+ATTN_SPLIT = 4  # fc_attention precision: split-fp32 attention (x3 rows out)
+# KIND_X3: element-kind argument of the row kernels / attention: x3 rows out (three bf16 planes, csrc/common.h)
 
 
 def _x3_empty(rows: int, cols: int, device) -> torch.Tensor:
@@ -96,9 +98,11 @@ def add_layernorm(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, bet
 
 
 def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False,
-              three_plane: bool = False) -> torch.Tensor:
+              three_plane: bool = False, split: bool = False) -> torch.Tensor:
     """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]; `three_plane`
-    (float32 qkv, non-causal, 113..224 tokens): x3 rows [.., 4 * heads * 64] of the fp32 result."""
+    (float32 qkv, non-causal, 113..224 tokens): x3 rows [.., 4 * heads * 64] of the fp32 result; `split` (193..208 tokens):
+    x3 rows too, both products as six bf16 products per fp32 product on the bf16 matrix cores (fp32 accuracy)."""
+    three_plane = three_plane or split
     _dev(qkv, "qkv", torch.float32 if three_plane else None)
     D = heads * 64
     if qkv.shape != (n_seq * seq_len, 3 * D):
@@ -106,7 +110,7 @@ def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: b
     out = (_x3_empty(n_seq * seq_len, D, qkv.device) if three_plane
            else torch.empty((n_seq * seq_len, D), dtype=qkv.dtype, device=qkv.device))
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().fc_attention(KIND_X3 if three_plane else _KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(),
+        _lib.check(_lib.load().fc_attention(ATTN_SPLIT if split else KIND_X3 if three_plane else _KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(),
                                             n_seq, seq_len, heads, int(causal), _lib.current_stream()), "fc_attention")
     return out
 

@@ -171,7 +171,10 @@ FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64
 /* Multi-head attention over packed rows: qkv [n_seq * S, 3 * heads * 64] (q | k | v, head dim 64) -> out
  * [n_seq * S, heads * 64], softmax(q k^T / 8 [+ causal mask]) v per (sequence, head), as nn.MultiheadAttention inside
  * slip.py:366-380.  Any S in fp32; bf16: causal up to 224 tokens, non-causal any S (K/V streamed beyond 224).
- * precision 3: fp32 qkv in, x3 rows out (fc_split3 layout; non-causal, 113..224 tokens). */
+ * precision 3: fp32 qkv in, x3 rows out (fc_split3 layout; non-causal, 113..224 tokens), the fp32 kernel's values.
+ * precision 4: the same operands and layout, both products formed as six bf16 products per fp32 product on the bf16 matrix
+ * cores (fc_gemm_split3's arithmetic; fp32 accuracy, not the fp32 kernel's bits; non-causal, 193..208 tokens): the attention
+ * of the split_gemm mode. */
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);

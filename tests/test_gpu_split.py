@@ -118,6 +118,55 @@ def test_layernorm_and_attention_write_three_plane_rows():
         ops.attention(qkv[: 50 * n_seq].contiguous(), n_seq, 50, heads, three_plane=True)  # not a streaming-block length
 
 
+def _attention_f64(qkv, n_seq, S, heads):
+    q, k, v = (t.reshape(n_seq, S, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.chunk(3, dim=1))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(n_seq * S, heads * 64)
+
+
+@pytest.mark.parametrize("S", [197, 193, 208])
+def test_split_attention_has_fp32_accuracy(S):
+    """fc_attention precision 4: softmax(q k^T / 8) v with both products as six bf16 products per fp32 product (the attention
+    of the split-fp32 mode).  Against float64 it must be as accurate as the fp32-MFMA kernel; its output must be the
+    canonical x3 image of an fp32 tensor; a (sequence, head) pair's result must not depend on how many pairs the persistent
+    workgroups walk over (300 sequences: 3600 pairs on 256 workgroups, the prefetch across passes) nor on the run."""
+    heads = 12
+    g = torch.Generator(device=DEV).manual_seed(S)
+    n_seq = 300
+    qkv = torch.randn(n_seq * S, 3 * heads * 64, device=DEV, generator=g) * 2.0   # scores of +-30: peaked rows too
+    qkv[: S, : heads * 64] *= 3.0
+    o3 = ops.attention(qkv, n_seq, S, heads, split=True)
+    p = ops.x3_planes(o3)
+    o = p[0].float() + p[1].float() + p[2].float()
+    _check_image(o3, o)
+    lines = o3.view(n_seq * S, heads * 4, 4, 16)
+    assert not lines[:, :, 3].any()                              # the fourth quarter of every line is zero
+    some = torch.cat([torch.arange(0, 3 * S), torch.arange(150 * S, 151 * S), torch.arange((n_seq - 2) * S, n_seq * S)]).to(DEV)
+    n_some = some.numel() // S
+    ref = _attention_f64(qkv[some], n_some, S, heads)
+    o32 = ops.attention(qkv, n_seq, S, heads)
+    scale = float(ref.abs().max())
+    e_split = float((o[some].double() - ref).abs().max()) / scale
+    e_f32 = float((o32[some].double() - ref).abs().max()) / scale
+    assert e_split < 5e-6 and e_split < 1.2 * e_f32 + 1e-7, (e_split, e_f32)
+    assert float((o - o32).abs().max()) / scale < 1e-5          # EVERY element, against the fp32-MFMA kernel
+    assert torch.equal(ops.attention(qkv, n_seq, S, heads, split=True), o3)  # run to run
+    few = 7                                                      # fewer pairs than workgroups: one pass each
+    assert torch.equal(ops.attention(qkv[: few * S].contiguous(), few, S, heads, split=True), o3[: few * S])
+    tail = qkv[(n_seq - few) * S:].contiguous()
+    assert torch.equal(ops.attention(tail, few, S, heads, split=True), o3[(n_seq - few) * S:])
+
+
+def test_split_attention_rejects_other_lengths():
+    qkv = torch.zeros(2 * 192, 3 * 768, device=DEV)
+    with pytest.raises(Exception, match="S=192"):
+        ops.attention(qkv, 2, 192, 12, split=True)
+    with pytest.raises(Exception, match="S=209"):
+        ops.attention(torch.zeros(2 * 209, 3 * 768, device=DEV), 2, 209, 12, split=True)
+    with pytest.raises(Exception, match="causal"):
+        ops.attention(torch.zeros(2 * 197, 3 * 768, device=DEV), 2, 197, 12, causal=True, split=True)
+
+
 @pytest.mark.parametrize("tag,dims", [("tiny", synth.TINY), ("vitb16", synth.VIT_B_16)])
 def test_towers_match_reference_fixtures(golden_dir, tag, dims, request):
     """The raw visual tower in split mode vs the fixtures produced by the reference's slip classes and by HF CLIP
