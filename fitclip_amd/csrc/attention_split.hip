@@ -82,14 +82,18 @@ constexpr int NKT = 13, NKR = NKT * 16;      // 16-key tiles / rows per plane
 constexpr int PL = NKR * 128;                // bytes per plane
 constexpr int OFF_V = 3 * PL;
 constexpr int NW = 8, NT = NW * 64;
-constexpr int NIT = (NKR * 8 + NT - 1) / NT;  // (key, 8-d chunk) staging items per thread and operand
+// Staging shares ((key, 8-d chunk) items of 64 lanes x N iterations per operand): the waves with one query tile (5..7) take
+// 6 iterations each, three of the five two-tile waves 3 each (3 * 384 + 3 * 192 = 1728 >= 1664 items), two stage nothing -
+// the two-tile waves carry twice the splits, exponentials and MFMAs of the others.
+constexpr int NIT16 = 6, NIT32 = 3;
 constexpr int ATTN_SPLIT_LDS = 6 * PL;
 // the six products, smallest terms first: (plane of the LDS operand, plane of the register operand)
 __device__ constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 
 // ABL (tools/attn_split_lab.hip only): 1 = no S products, 2 = no P.V products, 3 = no exponentials, 4 = no staging of K / V,
 // 10 = 1 + 2 + 3 (memory traffic, splits and barriers only), 11 = no output stores,
-// 20 = s_memtime stamps around the barriers of wave 0 of workgroup 0
+// 20 = s_memtime stamps around the barriers of wave 0 of workgroup 0, 30 / 31 = the waves that stage nothing are 0, 4 / 0, 2
+// instead of 0, 1
 template <int ABL>
 struct Flags {
   static constexpr bool kNoS = ABL == 1 || ABL == 10, kNoPV = ABL == 2 || ABL == 10, kNoExp = ABL == 3 || ABL == 10,
@@ -104,6 +108,7 @@ struct Ctx {
   int S, heads, D, n_items;
   long ld;
   int tid, lane, wave;
+  int stage0;  // first (key, chunk) staging item of this wave (wave-uniform), -1: this wave stages nothing
 
   __device__ __forceinline__ const float* item_base(int item) const {
     const int seq = item / heads, h = item - seq * heads;
@@ -111,21 +116,25 @@ struct Ctx {
   }
   // K or V of one (sequence, head) as fp32 into registers: staging item = (key, 8-d chunk c).  Padded keys (and the items
   // past the last row: loaded, never stored) read a valid row; padded keys are masked in the softmax.
-  __device__ __forceinline__ void load_kv(const float* base, int isv, f32x4 (&raw)[NIT][2]) const {
+  template <int N>
+  __device__ __forceinline__ void load_kv(const float* base, int isv, f32x4 (&raw)[N][2]) const {
+    if (stage0 < 0) return;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int item = it * NT + tid, key = item >> 3, c = item & 7;
+    for (int it = 0; it < N; ++it) {
+      const int item = stage0 + it * 64 + lane, key = item >> 3, c = item & 7;
       const float* src = base + (isv ? 2 * D : D) + (long)min(key, S - 1) * ld + c * 8;
       raw[it][0] = *reinterpret_cast<const f32x4*>(src);
       raw[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
     }
   }
   // ... and from the registers as three bf16 planes into LDS
-  __device__ __forceinline__ void store_kv(int isv, const f32x4 (&raw)[NIT][2]) const {
+  template <int N>
+  __device__ __forceinline__ void store_kv(int isv, const f32x4 (&raw)[N][2]) const {
+    if (stage0 < 0) return;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int item = it * NT + tid, key = item >> 3, c = item & 7;
-      if ((it + 1) * NT <= NKR * 8 || item < NKR * 8) {
+    for (int it = 0; it < N; ++it) {
+      const int item = stage0 + it * 64 + lane, key = item >> 3, c = item & 7;
+      if (item < NKR * 8) {
         bf16x8 p1, p2, p3;
         split3x8(raw[it][0], raw[it][1], p1, p2, p3);
         const int pos = isv ? ((((c >> 1) ^ ((key >> 1) & 3)) << 5) | ((c & 1) << 4)) : ((c ^ ((key >> 1) & 7)) << 4);
@@ -149,6 +158,7 @@ struct Ctx {
 template <int ABL>
 struct Tile16 {
   using F = Flags<ABL>;
+  static constexpr int NITW = NIT16;
   f32x4 qraw[2][2], sT[NKT], o[4];
   bf16x8 qf[3][2];
   float inv;
@@ -287,6 +297,7 @@ template <int ABL>
 struct Tile32 {
   using F = Flags<ABL>;
   static constexpr int NT32 = (NKR + 31) / 32;  // 7 key tiles of 32; rows 208 .. 223 do not exist (masked, clamped reads)
+  static constexpr int NITW = NIT32;
   f32x4 qraw[4][2];
   f32x16 sT[NT32], o[2];
   bf16x8 qf[3][4];
@@ -415,22 +426,31 @@ struct Tile32 {
       }
     }
   }
+  // o[m][4 b4 + j] = O(query c, d = 32 m + 8 b4 + 4 hh + j): of the 16 columns of group n = 2 m + (b4 >> 1) this lane holds
+  // 4 hh .. + 3 (b4 even) and 8 + 4 hh .. + 3 (b4 odd), its partner lane (c, 1 - hh) the other two quads.  One
+  // v_permlane32_swap per register hands the lower lane columns 0 .. 7 and the upper lane 8 .. 15 of every plane: 16-byte
+  // stores, half the store instructions (the address unit works per 128-byte line a store touches - 32 per instruction
+  // here - and the 8-byte version kept the waves waiting on it).
   __device__ __forceinline__ void store_out(const Ctx& x, int item) const {
     const int seq = item / x.heads, h = item - seq * x.heads;
-    if (query < x.S && (!F::kNoStore || inv == 123.f)) {
-      char* line = x.out + ((long)seq * x.S + query) * ((long)x.D * 8) + (long)(h * 4) * X3_GROUP_BYTES + hh * 8;
+    if (F::kNoStore && inv != 123.f) return;
+    char* line = x.out + ((long)seq * x.S + min(query, x.S - 1)) * ((long)x.D * 8) + (long)(h * 4) * X3_GROUP_BYTES + hh * 16;
+    const bool live = query < x.S;  // (the swaps need every lane)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 4; ++n) {
+      const int m = n >> 1, be = 2 * (n & 1);
+      bf16x4 e[3], od[3];
+      split3x4(f32x4{o[m][4 * be], o[m][4 * be + 1], o[m][4 * be + 2], o[m][4 * be + 3]} * inv, e[0], e[1], e[2]);
+      split3x4(f32x4{o[m][4 * be + 4], o[m][4 * be + 5], o[m][4 * be + 6], o[m][4 * be + 7]} * inv, od[0], od[1], od[2]);
 #pragma unroll
-        for (int b4 = 0; b4 < 4; ++b4) {  // four consecutive d: group n = 2 m + (b4 >> 1), columns 8 (b4 & 1) + 4 hh .. + 3
-          bf16x4 p1, p2, p3;
-          split3x4(f32x4{o[m][4 * b4], o[m][4 * b4 + 1], o[m][4 * b4 + 2], o[m][4 * b4 + 3]} * inv, p1, p2, p3);
-          char* q = line + (2 * m + (b4 >> 1)) * X3_GROUP_BYTES + (b4 & 1) * 16;
-          *reinterpret_cast<bf16x4*>(q) = p1;
-          *reinterpret_cast<bf16x4*>(q + 32) = p2;
-          *reinterpret_cast<bf16x4*>(q + 64) = p3;
-          *reinterpret_cast<bf16x4*>(q + 96) = bf16x4{};
-        }
+      for (int p = 0; p < 3; ++p) {
+        const u32x2 ue = __builtin_bit_cast(u32x2, e[p]), uo = __builtin_bit_cast(u32x2, od[p]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(ue[0], uo[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(ue[1], uo[1], false, false);
+        // lower lanes: (own quad, partner's quad) of the even b4 = columns 0 .. 7; upper lanes: columns 8 .. 15
+        if (live) *reinterpret_cast<u32x4*>(line + n * X3_GROUP_BYTES + p * 32) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+      if (live) *reinterpret_cast<u32x4*>(line + n * X3_GROUP_BYTES + 96) = u32x4{0u, 0u, 0u, 0u};
     }
   }
 };
@@ -445,7 +465,7 @@ __device__ __forceinline__ void run_wave(const Ctx& c) {
   using F = Flags<ABL>;
   Tile t;
   t.init(c);
-  f32x4 raw[NIT][2];
+  f32x4 raw[Tile::NITW][2];
   int nstamp = 0;
   auto bar = [&]() {
     const bool on = ABL == 20 && blockIdx.x == 0 && c.wave == 0 && c.lane == 0;
@@ -499,6 +519,20 @@ __global__ void __launch_bounds__(NT) attn_split_kernel(const float* __restrict_
   c.tid = threadIdx.x, c.lane = c.tid & 63;
   c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
   if (blockIdx.x >= n_items) return;  // (the launcher never asks for more workgroups than items)
+  {
+    const int idle0 = 0, idle1 = ABL == 30 ? 4 : ABL == 31 ? 2 : 1;  // (measured: 0, 1 and 0, 2 equal, 0, 4 1.5 % slower)
+    if (c.wave >= 5) {
+      c.stage0 = (c.wave - 5) * (NIT16 * 64);
+    } else if (c.wave == idle0 || c.wave == idle1) {
+      c.stage0 = -1;
+    } else {
+      int slot = 0;
+#pragma unroll
+      for (int w = 0; w < 5; ++w)
+        if (w < c.wave && w != idle0 && w != idle1) ++slot;
+      c.stage0 = 3 * NIT16 * 64 + slot * (NIT32 * 64);
+    }
+  }
   if (c.wave + NW < NKT)  // wave-uniform: waves 0 .. 4 carry two query tiles (w, w + 8)
     run_wave<ABL, Tile32<ABL>>(c);
   else

@@ -136,6 +136,8 @@ int main(int argc, char** argv) {
     printf("fp32-MFMA blocks kernel (x3 out)                        %8.3f ms\n", ms);
   }
   run_split<0>(qkv, o_new, n_seq, S, heads, reps, "product kernel");
+  run_split<30>(qkv, o_new, n_seq, S, heads, reps, "waves 0, 4 stage nothing (instead of 0, 1)");
+  run_split<31>(qkv, o_new, n_seq, S, heads, reps, "waves 0, 2 stage nothing");
   run_split<1>(qkv, o_new, n_seq, S, heads, reps, "no S MFMAs");
   run_split<2>(qkv, o_new, n_seq, S, heads, reps, "no P.V MFMAs");
   run_split<3>(qkv, o_new, n_seq, S, heads, reps, "no exponentials");
