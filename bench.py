@@ -447,8 +447,9 @@ def run_split_mode(sd, video, text, args, shards, device, backend):
     other = aggregate(records)[1]
     return {
         "value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate; LayerNorm, "
-                 "softmax, residual stream, patch embedding and the text tower in plain fp32",
+        "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate (the visual "
+                 "tower's block GEMMs and attention products); LayerNorm, softmax arithmetic, residual stream, patch "
+                 "embedding and the text tower in plain fp32",
         "roofline": {"bound": "mfma", "kernel": f"gemm_split3_kernel<256x256><three bf16 planes per operand, six MFMA products "
                                                 f"per fp32 product, {epi_name}> M={M} N={N} K={K6 // 6} (x 6 products)",
                      "achieved": round(bf16_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
