@@ -76,6 +76,7 @@ GF_PER_TEXT = 5.960e9
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 EPI_BIAS, EPI_GELU = 0, 1
 EPI_NAMES = {0: "bias", 1: "bias_quickgelu", 2: "bias_residual", 3: "patch_embed", 4: "store_f32"}
+EPI_RESID = 2
 
 
 def host_cores() -> int:
@@ -338,7 +339,7 @@ def run_mode(precision, sd, video, text, args, shards, device, backend, full_det
     # launches of a step stay uninstrumented here, so this repetition runs within a fraction of a percent of the timed one
     # (both wall times are reported).  Which kernel dominates is decided by the fully instrumented step that follows.
     enc.model.profile(16384)
-    enc.model.profile_select(kind_mask=1, epilogue_mask=(1 << EPI_GELU) | (1 << EPI_BIAS))
+    enc.model.profile_select(kind_mask=1, epilogue_mask=(1 << EPI_GELU) | (1 << EPI_BIAS) | (1 << EPI_RESID))
     enc.model.profile_reset()
     repeat_elapsed, _ = timed_steps(step, args.steps, device, backend)
     timed_records = enc.model.profile_records()
@@ -432,14 +433,14 @@ def run_split_mode(sd, video, text, args, shards, device, backend):
     enc.overlap_text = overlap
     records = enc.model.profile_records()
     enc.model.profile(0)
-    six = [r for r in records if r["kind"] == 0 and r["epilogue"] in (6, 7) and r["ms"] > 0]
+    six = [r for r in records if r["kind"] == 0 and r["epilogue"] in (6, 7, 8) and r["ms"] > 0]
     by = defaultdict(lambda: [0.0, 0])
     for r in six:
         by[(r["epilogue"], r["N"], r["K"], r["M"])][0] += r["ms"]
         by[(r["epilogue"], r["N"], r["K"], r["M"])][1] += 1
     (epi, N, K6, M), (ms, cnt) = max(by.items(), key=lambda kv: kv[1][0])
     bf16_flops = 2.0 * M * N * K6  # executed on the bf16 pipe: six products per fp32 product
-    epi_name = {6: "bias_f32_out", 7: "bias_quickgelu_x3_out"}[epi]
+    epi_name = {6: "bias_f32_out", 7: "bias_quickgelu_x3_out", 8: "bias_residual_f32_out"}[epi]
     traffic, traffic_note = load_traffic("fp32x6", (M, N, K6), epi_name)
     six_ms = sum(r["ms"] for r in six)
     six_flops = sum(2.0 * r["M"] * r["N"] * r["K"] for r in six)

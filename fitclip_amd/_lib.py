@@ -15,7 +15,7 @@ _CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ.get("FITCLIP_HIP_LIB", _CSRC / "libfitclip_hip.so"))
 
 PREC_F32, PREC_BF16 = 0, 1
-EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_DGELU_T, EPI_BIAS_F32, EPI_GELU_X3 = range(8)
+EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_DGELU_T, EPI_BIAS_F32, EPI_GELU_X3, EPI_RESID3_F32 = range(9)
 
 
 class FitclipHipError(RuntimeError):

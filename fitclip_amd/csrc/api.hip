@@ -221,8 +221,10 @@ Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, b
 }
 
 // The 12 pre-LN residual blocks followed by the final LayerNorm of the pooled rows (CLS rows: pool_idx == nullptr,
-// row i * pool_step; EOT rows: pool_idx).  Every projection GEMM writes its output ("delta", element type T) with a
-// plain store epilogue; the residual add x += delta is folded into the LayerNorm that follows it.
+// row i * pool_step; EOT rows: pool_idx).  fp32: out_proj and c_proj add their result to the residual stream in their
+// epilogue (EPI_RESID_F32) and a plain LayerNorm follows.  bf16 (and the pooled rows of a pruned last block): the projection
+// writes its output ("delta", element type T) with a plain store epilogue and the residual add x += delta is folded into
+// the LayerNorm that follows it.  Both forms perform the same fp32 add: same bits.
 //
 // cfg.prune_last_block: the towers only read the pooled row of each sequence after the last block, so in the last block
 // everything after the attention (out_proj, LayerNorm 2, c_fc, c_proj: 72 % of a block's FLOPs) is only computed for
@@ -241,12 +243,21 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
   const int esz = h->esz;
   const size_t nl = t.blocks.size();
   const long xs_pool = pool_idx ? w : pool_step * w;  // x row stride seen through the pooling index
+  // fp32: out_proj and c_proj update the residual stream IN their epilogue (EPI_RESID_F32: x += acc + bias, the same fp32 add
+  // the fused add+LayerNorm did), so the LayerNorm behind them reads one fp32 row and writes none back: 8 instead of 16 bytes
+  // per element in a pass that is HBM-bound, against 4 more bytes read by a GEMM that is MFMA-bound.  Same bits.
+  // (bf16 keeps the delta + fused add+LayerNorm form: its pipelined kernel has no fp32-output epilogue.)
+  static const bool no_fuse = getenv("FITCLIP_NO_RESID_EPILOGUE") != nullptr;  // A/B switch
+  const bool fuse = kind == PREC_F32 && !no_fuse;
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
     if (l == 0 && entry) {
       FC_TRY(launch_layernorm_pair(s.x, entry->cls, entry->pos0, S, entry->pre_w, entry->pre_b, b.ln1_w, b.ln1_b, s.xn,
                                    kind, M, w, st));
     } else if (l == 0) {
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
+    } else if (fuse) {
+      ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
@@ -271,6 +282,16 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
       FC_TRY(gemm(h, EPI_BIAS_T, hc, b.proj_w, b.proj_b, d2, nullptr, n_seq, w, 4 * w, w, 0, st));
       return launch_add_layernorm(s.x, xs_pool, d2, w, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 1, st);
     }
+    if (fuse) {
+      FC_TRY(gemm(h, EPI_RESID_F32, s.xn, b.out_w, b.out_b, s.x, nullptr, M, w, w, w, 0, st));
+      {
+        ProfScope ps(h, st, 2, M, w, 1);
+        FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, st));
+      }
+      FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
+      FC_TRY(gemm(h, EPI_RESID_F32, s.big, b.proj_w, b.proj_b, s.x, nullptr, M, w, 4 * w, w, 0, st));
+      continue;
+    }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.out_w, b.out_b, s.big, nullptr, M, w, w, w, 0, st));
     {
       ProfScope ps(h, st, 2, M, w, 1);
@@ -279,14 +300,16 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
     FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
     FC_TRY(gemm(h, EPI_BIAS_T, s.big, b.proj_w, b.proj_b, s.xn, nullptr, M, w, 4 * w, w, 0, st));
   }
+  if (fuse) return launch_layernorm(s.x, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);
   // the last c_proj delta is still pending in s.xn: fold it into the final LayerNorm of the pooled rows
   return launch_add_layernorm(s.x, xs_pool, s.xn, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 0, st);
 }
 
 // ---- split-fp32 visual tower (cfg.split_gemm): the same block sequence with the four big GEMMs on the bf16 matrix
 // cores over three-plane operands (gemm_split3.h, common.h).  Producers write x3 rows directly: LayerNorm (KIND_X3), the
-// fp32 attention kernel, c_fc's QuickGELU epilogue (EPI_GELU_X3); QKV / out_proj / c_proj return fp32 (EPI_BIAS_F32).
-// Everything else - residual stream, LayerNorm statistics, softmax - is the fp32 path's code.
+// attention kernel (attention_split.hip: its two products in the same arithmetic), c_fc's QuickGELU epilogue (EPI_GELU_X3);
+// QKV returns fp32 (EPI_BIAS_F32), out_proj / c_proj add to the fp32 residual stream in place (EPI_RESID3_F32).
+// Everything else - residual stream, LayerNorm statistics, softmax arithmetic - is the fp32 path's code.
 int gemm_x3(fc_handle* h, int epi, const void* A3, const void* W3, const float* bias, void* C, int M, int N, int K,
             int ldc, hipStream_t st) {
   GemmArgs a{};
@@ -313,6 +336,10 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
   const int M = n_seq * S;
   const long ld3 = x3_row_elems(w);
   const size_t nl = t.blocks.size();
+  // out_proj and c_proj update the residual stream in their epilogue (EPI_RESID3_F32, as the fp32 path's EPI_RESID_F32): the
+  // LayerNorm behind them reads one fp32 row and writes the x3 rows - 12 instead of 20 bytes per element
+  static const bool no_fuse = getenv("FITCLIP_NO_RESID_EPILOGUE") != nullptr;  // A/B switch
+  const bool fuse = !no_fuse;
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
     if (l == 0) {
@@ -320,7 +347,8 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
                                    KIND_X3, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
+      if (fuse) FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, st));
+      else FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
     }
     FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.in_w3, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
     {
@@ -335,16 +363,20 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
         FC_TRY(launch_split3_rows(s.d, w, s.xn, ld3, M, w, st));
       }
     }
-    FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.out_w3, b.out_b, s.d, M, w, w, w, st));
+    if (fuse) FC_TRY(gemm_x3(h, EPI_RESID3_F32, s.xn, b.out_w3, b.out_b, s.x, M, w, w, w, st));
+    else FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.out_w3, b.out_b, s.d, M, w, w, w, st));
     {
       ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
+      if (fuse) FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, st));
+      else FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
     }
     FC_TRY(gemm_x3(h, EPI_GELU_X3, s.xn, b.fc_w3, b.fc_b, s.big, M, 4 * w, w, (int)x3_row_elems(4 * w), st));
-    FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.big, b.proj_w3, b.proj_b, s.d, M, w, 4 * w, w, st));
+    if (fuse) FC_TRY(gemm_x3(h, EPI_RESID3_F32, s.big, b.proj_w3, b.proj_b, s.x, M, w, 4 * w, w, st));
+    else FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.big, b.proj_w3, b.proj_b, s.d, M, w, 4 * w, w, st));
   }
-  // the last c_proj delta is still pending in s.d: fold it into the final LayerNorm of the pooled rows
   const long xs_pool = pool_step * w;
+  if (fuse) return launch_layernorm(s.x, xs_pool, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
+  // the last c_proj delta is still pending in s.d: fold it into the final LayerNorm of the pooled rows
   return launch_add_layernorm(s.x, xs_pool, s.d, xs_pool, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, 0, 0, st);
 }
 

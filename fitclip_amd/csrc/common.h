@@ -44,6 +44,7 @@ enum Epilogue : int {
   EPI_DGELU_T = 5,    // C(T)   = acc * quickgelu'(aux(T)[m, n])   (backward of c_fc's activation; aux laid out as C)
   EPI_BIAS_F32 = 6,   // gemm_split3 only: C(f32) = acc + bias                  (three-plane operands in, fp32 out)
   EPI_GELU_X3 = 7,    // gemm_split3 only: C(x3 rows [M, 4 N bf16]) = three_planes(quickgelu(acc + bias))   (the next GEMM's A operand)
+  EPI_RESID3_F32 = 8, // gemm_split3 only: C(f32) += acc + bias           (three-plane operands in; the residual stream updated in place)
 };
 
 // ---- split-fp32 operands.  An fp32 number is exactly the sum of three bf16 numbers, x = p1 + p2 + p3 (p1 = bf16(x),

@@ -119,7 +119,7 @@ bool pipelined_ok(const GemmArgs& a) {
 template <typename T>
 int resolve_tile(int epi, const GemmArgs& a, int tile) {
   if (tile != 0) return tile;
-  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || (epi == EPI_DGELU_T && sizeof(T) == 4);
+  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || ((epi == EPI_DGELU_T || epi == EPI_RESID_F32) && sizeof(T) == 4);
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
   return t256 >= 512 ? 2 : 1;
@@ -128,7 +128,7 @@ int resolve_tile(int epi, const GemmArgs& a, int tile) {
 // tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (BIAS_T / GELU_T only)
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
-  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4);
+  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || ((EPI == EPI_DGELU_T || EPI == EPI_RESID_F32) && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
     if constexpr (kHasPipelined) {
@@ -152,7 +152,8 @@ int launch_epi(int epi, const GemmArgs& a, int tile, hipStream_t stream) {
     case EPI_STORE_F32: return launch_tile<T, EPI_STORE_F32>(a, tile, stream);
     case EPI_DGELU_T: return launch_tile<T, EPI_DGELU_T>(a, tile, stream);
     case EPI_BIAS_F32:
-    case EPI_GELU_X3: return fail(FC_EINVAL, "gemm: epilogue %d belongs to the three-plane split-fp32 GEMM (fc_gemm_split3)", epi);
+    case EPI_GELU_X3:
+    case EPI_RESID3_F32: return fail(FC_EINVAL, "gemm: epilogue %d belongs to the three-plane split-fp32 GEMM (fc_gemm_split3)", epi);
   }
   return fail(FC_EINVAL, "gemm: unknown epilogue %d", epi);
 }

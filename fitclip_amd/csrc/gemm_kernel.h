@@ -171,9 +171,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   };
 
   const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
-  // The two store epilogues start the accumulators from the bias (as the pipelined kernel does, so both kernels
-  // produce bit-identical results and a row's value does not depend on which one the batch size selects).
-  constexpr bool kBiasInit = EPI == EPI_BIAS_T || EPI == EPI_GELU_T;
+  // The two store epilogues and the residual update start the accumulators from the bias (as the pipelined kernel does, so
+  // both kernels produce bit-identical results and a row's value does not depend on which one the batch size selects).
+  constexpr bool kBiasInit = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32;
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   const int nk = g.K / BKE;
   // the two block-GEMM epilogues use the rotated K order of gemm_pipelined_kernel (bit-identical results); scoring
   // (EPI_STORE_F32) and patch embedding keep the natural order, so a score does not depend on its column position
-  const int rot = (EPI == EPI_BIAS_T || EPI == EPI_GELU_T) ? (n0 >> 8) % nk : 0;
+  const int rot = kBiasInit ? (n0 >> 8) % nk : 0;
   auto krot = [&](int kt) { return kt + rot >= nk ? kt + rot - nk : kt + rot; };
   stage_load(0, krot(0));
   for (int kt = 0; kt < nk; ++kt) {
@@ -257,8 +257,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
         store4<float>(reinterpret_cast<float*>(g.C) + orow * g.ldc + n, v);
       } else if constexpr (EPI == EPI_RESID_F32) {
         float* p = reinterpret_cast<float*>(g.C) + orow * g.ldc + n;
-        v += *reinterpret_cast<const f32x4*>(g.bias + n);
-        v += *reinterpret_cast<const f32x4*>(p);
+        v = *reinterpret_cast<const f32x4*>(p) + v;  // (the accumulator started from the bias)
         store4<float>(p, v);
       } else if constexpr (EPI == EPI_DGELU_T) {
         const f32x4 pre = load4<T>(reinterpret_cast<const T*>(g.aux) + orow * g.ldc + n);
@@ -360,7 +359,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
-  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || (EPI == EPI_DGELU_T && sizeof(T) == 4), "epilogue");
+  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || ((EPI == EPI_DGELU_T || EPI == EPI_RESID_F32) && sizeof(T) == 4), "epilogue");
   // the counted wait behind the epilogue stores needs LPW + NST to fit the 6-bit vmcnt; tilings with more stores per wave
   // (4 waves of 128x128) wait for everything at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;
@@ -672,6 +671,28 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
         // 8 rows x 128 contiguous bytes per store instruction - the same number of store instructions (FM * FN).
         char* stg = smem + OFF_STG + wave * 2048;
         const int rrow = lane >> 3, rch = lane & 7;
+        // EPI_RESID_F32 (C += acc + bias: the residual stream updated in place, so the LayerNorm behind the projection reads
+        // ONE fp32 row instead of row + delta and writes no row back): every lane adds the 16 bytes of C it is about to
+        // overwrite.  They are requested RWIN row-tiles ahead (RWIN * FN loads in flight per lane: the fragment registers
+        // of the K loop are free here), whole lines per instruction like the stores, and non-temporal like them: the 1 GB
+        // stream must not push the operand panels out of L2.
+        constexpr int RWIN = 4;
+        f32x4 xres[EPI == EPI_RESID_F32 ? RWIN : 1][FN / 2][2];
+        auto resid_load = [&](int i, f32x4 (&dst)[FN / 2][2]) {
+#pragma unroll
+          for (int jj = 0; jj < FN / 2; ++jj)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int mo = cm0 + wm * TM + i * 16 + h * 8 + rrow, no = cn0 + wn * TN + jj * 32 + rch * 4;
+              dst[jj][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (interior || (mo < g.M && no < g.N))
+                dst[jj][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const TOUT*>(g.C) + (size_t)mo * g.ldc + no));
+            }
+        };
+        if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+          for (int i = 0; i < RWIN && i < FM; ++i) resid_load(i, xres[i]);
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int m = cm0 + wm * TM + i * 16 + r;
@@ -700,7 +721,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const int row = h * 8 + rrow;
-              const f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+              f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+              if constexpr (EPI == EPI_RESID_F32) val = xres[i % RWIN][jj][h] + val;
               const int mo = cm0 + wm * TM + i * 16 + row, no = cn0 + wn * TN + jj * 32 + rch * 4;
               if (interior || (mo < g.M && no < g.N)) {
                 f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<TOUT*>(g.C) + (size_t)mo * g.ldc + no);
@@ -708,6 +730,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
                 else __builtin_nontemporal_store(val, dst);
               }
             }
+          }
+          if constexpr (EPI == EPI_RESID_F32) {
+            if (i + RWIN < FM) resid_load(i + RWIN, xres[i % RWIN]);
           }
         }
       }

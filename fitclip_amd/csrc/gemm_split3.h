@@ -45,7 +45,7 @@ constexpr int prod_w(int x) { return x == 1 || x == 3 ? 1 : (x == 4 ? 2 : 0); }
 // SPREAD: 0 = the six LDS-DMA pieces a wave contributes to K-step k + 3 are issued in one burst at the hand-over of step k;
 // 1 = they are issued during step k + 1, two behind each of its first three MFMA groups (the stage is free since the
 // hand-over of step k; they still have more than a K-step to land).
-template <int EPI, int ABL = 0, int SPREAD = 0>
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4>
 __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 x 64 per wave
@@ -56,11 +56,12 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   constexpr int OFF_BIAS = 3 * STAGE;              // 2 x 1 KiB behind the three stages
   constexpr int PATCH = STAGE / NW;                // 6 KiB of the released stage per wave during the epilogue
   constexpr bool kOutX3 = EPI == EPI_GELU_X3;
+  constexpr bool kResid = EPI == EPI_RESID3_F32;   // C += acc + bias (fp32, in place)
   constexpr int NST = kOutX3 ? FM * FN * 2 * 4 : FM * FN * 4;  // store instructions per wave and interior tile: 64 / 32
   // the counted wait behind the epilogue stores needs 2 LPW + NST to fit the 6-bit vmcnt; the x3 epilogue (whole 128-byte lines:
   // 64 stores) waits for its stores at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;
-  static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X3, "epilogue");
+  static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X3 || EPI == EPI_RESID3_F32, "epilogue");
   static_assert(32 * 128 <= PATCH, "output patch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -329,6 +330,26 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
         // f32 outputs: a 32 x 32 tile goes through the wave's 32-row x 128-byte patch (chunk ^ (row & 7): conflict-free
         // both ways) and leaves as 8 rows x 128 contiguous bytes per store instruction
         const int rrow = lane >> 3, rch = lane & 7;
+        // EPI_RESID3_F32: every lane adds the 16 bytes of C it is about to overwrite (the residual stream, updated in place: the
+        // LayerNorm behind the projection then reads ONE fp32 row and writes no row back).  They are requested RWIN tiles ahead
+        // - whole lines per instruction and non-temporal, like the stores (the stream must not push the operand panels out of
+        // L2); the fragment registers of the K loop are free here.
+        constexpr int RWIN = RW, NT = FM * FN;
+        f32x4 xres[kResid ? RWIN : 1][4];
+        auto resid_load = [&](int tl, f32x4 (&dst)[4]) {
+          const int i = tl / FN, j = tl % FN;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int mo = cm0 + wm * TM + i * 32 + s * 8 + rrow, no = cn0 + wn * TN + j * 32 + rch * 4;
+            dst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (interior || (mo < g.M && no < g.N))
+              dst[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (size_t)mo * g.ldc + no));
+          }
+        };
+        if constexpr (kResid) {
+#pragma unroll
+          for (int tl = 0; tl < RWIN && tl < NT; ++tl) resid_load(tl, xres[tl]);
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -341,10 +362,16 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               const int row = s * 8 + rrow;
-              const f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+              f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+              if constexpr (kResid) val = xres[(i * FN + j) % RWIN][s] + val;
               const int mo = cm0 + wm * TM + i * 32 + row, no = cn0 + wn * TN + j * 32 + rch * 4;
-              if (interior || (mo < g.M && no < g.N))
-                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)mo * g.ldc + no));
+              if (interior || (mo < g.M && no < g.N)) {
+                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)mo * g.ldc + no);
+                __builtin_nontemporal_store(val, dst);
+              }
+            }
+            if constexpr (kResid) {
+              if (i * FN + j + RWIN < NT) resid_load(i * FN + j + RWIN, xres[(i * FN + j) % RWIN]);
             }
           }
         }

@@ -19,13 +19,13 @@ int cu_count() {
   return cus;
 }
 
-template <int EPI>
+template <int EPI, int RW = 4>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = 3 * 512 * 96 + 2048;  // three stages (the epilogue borrows the released one) + two bias slices
   // SPREAD = 1: the LDS-DMA pieces of a K-step are issued two at a time behind MFMA groups of the step before (lab: 4 - 8 % over
   // one burst of six per wave at the hand-over - with the bursts the L1's pending-miss queue fills, the TA stalls, and a wave
   // stuck on a DMA instruction issues no MFMAs: TCP_PENDING_STALL_CYCLES 24 % of the launch, tools/split3_lab + rocprofv3)
-  auto kern = gemm_split3_kernel<EPI, 0, 1>;
+  auto kern = gemm_split3_kernel<EPI, 0, 1, RW>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split3: cannot raise dynamic LDS to %d bytes", lds);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
@@ -86,6 +86,11 @@ int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream) {
     case EPI_BIAS_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split3: ldc=%d", a.ldc);
       return launch_one<EPI_BIAS_F32>(a, stream);
+    case EPI_RESID3_F32:
+      if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split3: ldc=%d", a.ldc);
+      // two tiles of the stream in flight: windows of 2, 3 and 4 measure the same (709 / 708 / 707 pairs/s on the bench step),
+      // and the wider ones spill - the first fragments of the next tile are live across the epilogue
+      return launch_one<EPI_RESID3_F32, 2>(a, stream);
     case EPI_GELU_X3:
       if (a.ldc % 64 || a.ldc < x3_row_elems(a.N) || ((uintptr_t)a.C & 127))
         return fail(FC_EINVAL, "gemm_split3: the x3 output needs 128-byte aligned rows of >= 4 N bf16 (ldc=%d)", a.ldc);

@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X3, EPI_PATCH_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
+from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X3, EPI_PATCH_F32, EPI_RESID3_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
                    PREC_BF16, PREC_F32)
 
 _KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
@@ -135,10 +135,12 @@ def x3_planes(x3: torch.Tensor):
     return tuple(v[:, :, i].reshape(x3.shape[0], -1) for i in range(3))
 
 
-def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, epilogue: int = EPI_BIAS_F32) -> torch.Tensor:
+def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, epilogue: int = EPI_BIAS_F32,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """epilogue(A @ W^T) for x3 operands a3 [M, 4 K], w3 [N, 4 K] (`split3` images or the x3 outputs of LayerNorm / attention
     / a previous EPI_GELU_X3 GEMM): six bf16 MFMA products per fp32 product, fp32 accumulate (fc_gemm_split3).
-    EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X3 -> x3 rows [M, 4 N] of QuickGELU(A @ W^T + bias)."""
+    EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X3 -> x3 rows [M, 4 N] of QuickGELU(A @ W^T + bias); EPI_RESID3_F32: `out`
+    (float32 [M, N]) += A @ W^T + bias, in place."""
     _dev(a3, "a3", torch.bfloat16), _dev(w3, "w3", torch.bfloat16), _dev(bias, "bias", torch.float32)
     if a3.dim() != 2 or w3.dim() != 2 or a3.shape[1] != w3.shape[1] or a3.shape[1] % 64:
         raise ValueError(f"x3 operands need matching [rows, 4 K] shapes, got {tuple(a3.shape)} and {tuple(w3.shape)}")
@@ -147,8 +149,12 @@ def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, epilogue
         out = _x3_empty(M, N, a3.device)
     elif epilogue == EPI_BIAS_F32:
         out = torch.empty((M, N), dtype=torch.float32, device=a3.device)
+    elif epilogue == EPI_RESID3_F32:
+        if out is None or out.shape != (M, N):
+            raise ValueError("the residual epilogue accumulates into `out` [M, N]")
+        _dev(out, "out", torch.float32)
     else:
-        raise ValueError("gemm_split3 has the epilogues EPI_BIAS_F32 and EPI_GELU_X3")
+        raise ValueError("gemm_split3 has the epilogues EPI_BIAS_F32, EPI_GELU_X3 and EPI_RESID3_F32")
     with torch.cuda.device(a3.device):
         _lib.check(_lib.load().fc_gemm_split3(epilogue, a3.data_ptr(), w3.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K,
                                               a3.stride(0), w3.stride(0), out.stride(0), _lib.current_stream()),

@@ -186,7 +186,8 @@ FC_API int fc_split3(const float* in, int64_t ld_in, void* out, int64_t ld_out, 
  * p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1 of every fp32 product, formed from registers on v_mfma_f32_32x32x16_bf16 and
  * accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-26 per product, at the bf16 matrix cores'
  * rate.  epilogue 6: C fp32 [M, N] = acc + bias (ldc floats); epilogue 7: C x3 rows [M, 4 N] = planes(QuickGELU(acc + bias))
- * (ldc bf16 positions), the next GEMM's A operand.  K % 32 == 0, K >= 64, N % 32 == 0; operands below 4 GiB. */
+ * (ldc bf16 positions), the next GEMM's A operand; epilogue 8: C fp32 [M, N] += acc + bias, in place (the residual update
+ * x = x + proj(..) of slip.py:382-385 in the projection's epilogue).  K % 32 == 0, K >= 64, N % 32 == 0; operands below 4 GiB. */
 FC_API int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, const float* bias, void* C, int32_t M, int32_t N,
                    int32_t K, int32_t lda, int32_t ldw, int32_t ldc, fc_stream stream);
 

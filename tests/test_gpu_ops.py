@@ -41,9 +41,19 @@ def test_gemm_all_epilogues(M, N, K, tile, dtype):
     out = ops.gemm(ad, wd, bd, ops.EPI_GELU_T, tile=tile)
     z = ref + bias.double()
     assert _rel(out, z * torch.sigmoid(1.702 * z)) < tol
-    if tile == 3:  # the persistent / pipelined kernel only has the two store epilogues
-        return
     resid = _rand(M, N, seed=4)
+    if tile == 3:  # the persistent / pipelined kernel has the two store epilogues and, in fp32, the residual update
+        if dtype == torch.float32:
+            # C += acc + bias in place: the bits of the bias epilogue followed by the fp32 add (what the fused
+            # add+LayerNorm did), and the bits of the plain kernels - a row does not depend on the kernel the batch selects
+            acc = resid.to(DEV).clone()
+            ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=3)
+            assert torch.equal(acc, resid.to(DEV) + ops.gemm(ad, wd, bd, ops.EPI_BIAS_T, tile=3))
+            for other in (1, 2):
+                acc2 = resid.to(DEV).clone()
+                ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc2, tile=other)
+                assert torch.equal(acc2, acc)
+        return
     acc = resid.to(DEV).clone()
     ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=tile)
     assert _rel(acc, resid.double() + z) < (2e-6 if dtype == torch.float32 else 2e-6 + 0)

@@ -69,6 +69,22 @@ def test_six_product_gemm_has_fp32_accuracy(M, N, K):
     assert torch.equal(ops.gemm_split3(ops.split3(a[lo:].contiguous()), ops.split3(w), bias, ops.EPI_BIAS_F32), y3[lo:])
 
 
+@pytest.mark.parametrize("M,N,K", [(20000, 768, 768), (12345, 768, 3072), (300, 512, 64)])
+def test_residual_epilogue_is_the_bias_epilogue_plus_the_stream(M, N, K):
+    """EPI_RESID3_F32 (C += A . W^T + bias in place: what out_proj / c_proj run in the split mode) must give the bits of
+    EPI_BIAS_F32 followed by the fp32 add the fused add+LayerNorm did, on whole tiles and ragged last panels, and leave the
+    rows beyond M alone."""
+    g = torch.Generator(device=DEV).manual_seed(M + 1)
+    a3 = ops.split3(torch.randn(M, K, device=DEV, generator=g))
+    w3 = ops.split3(torch.randn(N, K, device=DEV, generator=g) / K ** 0.5)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M + 3, N, device=DEV, generator=g) * 5
+    want = x[:M] + ops.gemm_split3(a3, w3, bias, ops.EPI_BIAS_F32)
+    got = x.clone()
+    ops.gemm_split3(a3, w3, bias, ops.EPI_RESID3_F32, out=got[:M])
+    assert torch.equal(got[:M], want) and torch.equal(got[M:], x[M:])
+
+
 def test_gemm_split3_rejects_bad_operands():
     a3 = torch.zeros(64, 256, dtype=torch.bfloat16, device=DEV)
     bias = torch.zeros(48, device=DEV)

@@ -50,6 +50,8 @@ def one_kernel(a, needle, min_us, max_us, shape, epilogue):
     # split-fp32 GEMMs (precision fp32x6; K is given as 6 K, the bf16 products): three bf16 planes per operand value = 6 bytes;
     # fp32 or three-plane rows out
     out_b = M * N * (4 if epilogue.endswith("f32_out") else 6 if epilogue.endswith("x3_out") else esz)
+    if "residual" in epilogue:  # C += ..: the fp32 tile is read as well as written
+        out_b = 2 * M * N * 4
     res = {"kernel_substring": needle, "min_duration_us": min_us, "max_duration_us": max_us,
            "launches_fetch": len(f["FETCH_SIZE"]), "launches_write": len(w["WRITE_SIZE"]),
            "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b, "hbm_bytes_per_launch": fetch_b + write_b,

@@ -23,12 +23,13 @@ export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
 # (fp32: the 2048 frames of a bench step run as 1663 + 385: 1663 frames = 1280 panels of 256 rows = whole rounds of the 256 CUs; bf16 512)
-# c_fc (+QuickGELU) has its own instantiation; c_proj shares the bias instantiation with QKV / out_proj and is told
-# apart by its duration window (fp32 @ 1663 frames in the main pass: c_proj 11.4 ms, QKV 8.2, out_proj 3.0; bf16 @ 512: 0.40 / 0.32 / 0.12)
+# c_fc (+QuickGELU) has its own instantiation; c_proj shares one with out_proj (fp32: the residual epilogue, 2) or with QKV /
+# out_proj (bf16: the bias epilogue, 0) and is told apart by its duration window (fp32 @ 1663 frames in the main pass: c_proj
+# 11.4 ms, QKV 8.2, out_proj 3.0; bf16 @ 512: 0.40 / 0.32 / 0.12)
 if [ "$prec" = fp32 ]; then
   steps=3; chunk=1663; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
-  spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 0,|9800|1e9|$rows|768|3072|bias"
+  spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 2,|9800|1e9|$rows|768|3072|bias_residual"
 elif [ "$prec" = bf16 ]; then
   steps=5; chunk=512; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
@@ -36,11 +37,11 @@ elif [ "$prec" = bf16 ]; then
 else
   # fp32x6 = the split-fp32 leg of the fp32 bench run (the 2048 frames of a step run as 768 + 768 + 512; three-plane operands,
   # six bf16 products per fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation
-  # (epilogue 7; 3.4 ms at 768 frames, 2.3 at 512); c_proj shares epilogue 6 with QKV / out_proj and is the only one of them
-  # above 2.9 ms (at 768 frames: c_proj 3.2, QKV 2.55, out_proj 0.85)
+  # (epilogue 7; 3.4 ms at 768 frames, 2.3 at 512); c_proj shares epilogue 8 (residual update in place) with out_proj and is the
+  # only one of the two above 2.9 ms (at 768 frames: c_proj 3.2, out_proj 0.85; QKV, epilogue 6: 2.55)
   steps=3; chunk=768; rows=$((chunk * 197))
   spec_fc="gemm_split3_kernel<7,|3000|1e9|$rows|3072|4608|bias_quickgelu_x3_out"
-  spec_proj="gemm_split3_kernel<6,|2900|1e9|$rows|768|18432|bias_f32_out"
+  spec_proj="gemm_split3_kernel<8,|2900|1e9|$rows|768|18432|bias_residual_f32_out"
 fi
 if [ "$prec" = fp32x6 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"

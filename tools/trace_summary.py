@@ -41,6 +41,8 @@ def main():
         pipelined = re.search(r"gemm_pipelined_kernel<[^,]+, 256, 256, 2, 4, (\d),", name)
         if "gemm_pipelined_kernel" in name and ("Li256ELi256ELi2ELi4ELi0E" in name or (pipelined and pipelined.group(1) == "0")):
             label = "bias_gemm"
+        elif "gemm_pipelined_kernel" in name and ("Li256ELi256ELi2ELi4ELi2E" in name or (pipelined and pipelined.group(1) == "2")):
+            label = "resid_gemm"  # fp32: out_proj and c_proj update the residual stream in their epilogue
         elif "gemm_pipelined_kernel" in name and ("Li256ELi256ELi2ELi4ELi1E" in name or (pipelined and pipelined.group(1) == "1")):
             label = "c_fc"
         elif "attn_" in name:
@@ -59,14 +61,23 @@ def main():
     # (fp32 bench step: passes of 1663 + 385 frames; the shortest visual launch, out_proj of the short pass, runs 0.7 ms)
     cut = 500.0 if fp32 else 70.0
     cut_small = 100.0 if fp32 else 40.0
-    seq = 0
+    seq = seq2 = 0
+    fused = any(item[0] == "resid_gemm" for item in labelled)
     for item in labelled:
         if item[0] == "bias_gemm":
             if item[1] < cut:
                 item[0] = "text / short-pass gemm"
+            elif fused:
+                item[0] = "qkv"
             else:
                 item[0] = ("qkv", "out_proj", "c_proj")[seq % 3]
                 seq += 1
+        elif item[0] == "resid_gemm":
+            if item[1] < cut:
+                item[0] = "text / short-pass gemm"
+            else:
+                item[0] = ("out_proj", "c_proj")[seq2 % 2]
+                seq2 += 1
         elif item[0] == "c_fc" and item[1] < cut:
             item[0] = "text / short-pass gemm"
         elif item[0] in ("attention", "add_layernorm") and item[1] < cut_small:
