@@ -221,10 +221,10 @@ Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, b
 }
 
 // The 12 pre-LN residual blocks followed by the final LayerNorm of the pooled rows (CLS rows: pool_idx == nullptr,
-// row i * pool_step; EOT rows: pool_idx).  fp32: out_proj and c_proj add their result to the residual stream in their
-// epilogue (EPI_RESID_F32) and a plain LayerNorm follows.  bf16 (and the pooled rows of a pruned last block): the projection
-// writes its output ("delta", element type T) with a plain store epilogue and the residual add x += delta is folded into
-// the LayerNorm that follows it.  Both forms perform the same fp32 add: same bits.
+// row i * pool_step; EOT rows: pool_idx).  out_proj and c_proj add their result to the residual stream in their epilogue
+// (EPI_RESID_F32) and a plain LayerNorm follows.  The pooled rows of a pruned last block (and FITCLIP_NO_RESID_EPILOGUE=1,
+// the A/B switch): the projection writes its output ("delta", element type T) with a plain store epilogue and the residual
+// add x += delta is folded into the LayerNorm that follows it; in fp32 both forms perform the same fp32 add: same bits.
 //
 // cfg.prune_last_block: the towers only read the pooled row of each sequence after the last block, so in the last block
 // everything after the attention (out_proj, LayerNorm 2, c_fc, c_proj: 72 % of a block's FLOPs) is only computed for
@@ -243,12 +243,13 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
   const int esz = h->esz;
   const size_t nl = t.blocks.size();
   const long xs_pool = pool_idx ? w : pool_step * w;  // x row stride seen through the pooling index
-  // fp32: out_proj and c_proj update the residual stream IN their epilogue (EPI_RESID_F32: x += acc + bias, the same fp32 add
-  // the fused add+LayerNorm did), so the LayerNorm behind them reads one fp32 row and writes none back: 8 instead of 16 bytes
-  // per element in a pass that is HBM-bound, against 4 more bytes read by a GEMM that is MFMA-bound.  Same bits.
-  // (bf16 keeps the delta + fused add+LayerNorm form: its pipelined kernel has no fp32-output epilogue.)
+  // out_proj and c_proj update the residual stream IN their epilogue (EPI_RESID_F32: x += acc + bias), so the LayerNorm behind
+  // them reads one fp32 row and writes none back: fp32 8 instead of 16 bytes per element in a pass that is HBM-bound, against 4
+  // more bytes read by a GEMM that is MFMA-bound; the same fp32 add the fused add+LayerNorm did - same bits (+1.3 % on the bench
+  // step).  bf16: 6 instead of 12 bytes in the LayerNorm pass against 6 more in the GEMMs, which are closer to the memory there
+  // (+1.5 %); the stream receives the fp32 accumulator instead of its bf16 rounding.
   static const bool no_fuse = getenv("FITCLIP_NO_RESID_EPILOGUE") != nullptr;  // A/B switch
-  const bool fuse = kind == PREC_F32 && !no_fuse;
+  const bool fuse = !no_fuse;
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
     if (l == 0 && entry) {
@@ -267,6 +268,21 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
       FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
+    }
+    if (l + 1 == nl && h->cfg.prune_last_block && fuse) {
+      // the pooled rows of the attention output and of the residual stream, compact; then the block's tail as above
+      const size_t blk = align_up((size_t)n_seq * w * 4);
+      char* ao = s.big;                                   // [n, w] T   attention output
+      float* xp = reinterpret_cast<float*>(s.big + blk);  // [n, w] f32 residual stream
+      char* xc = s.big + 2 * blk;                         // [n, w] T   LayerNorm 2 output
+      char* hc = s.big + 3 * blk;                         // [n, 4w] T  MLP hidden
+      FC_TRY(launch_gather_rows(s.xn, pool_idx, pool_step, ao, n_seq, w * esz, st));
+      FC_TRY(launch_gather_rows(reinterpret_cast<const char*>(s.x), pool_idx, pool_step, reinterpret_cast<char*>(xp), n_seq, w * 4, st));
+      FC_TRY(gemm(h, EPI_RESID_F32, ao, b.out_w, b.out_b, xp, nullptr, n_seq, w, w, w, 0, st));
+      FC_TRY(launch_layernorm(xp, w, nullptr, b.ln2_w, b.ln2_b, xc, w, kind, n_seq, w, st));
+      FC_TRY(gemm(h, EPI_GELU_T, xc, b.fc_w, b.fc_b, hc, nullptr, n_seq, 4 * w, w, 4 * w, 0, st));
+      FC_TRY(gemm(h, EPI_RESID_F32, hc, b.proj_w, b.proj_b, xp, nullptr, n_seq, w, 4 * w, w, 0, st));
+      return launch_layernorm(xp, w, nullptr, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);
     }
     if (l + 1 == nl && h->cfg.prune_last_block) {
       const size_t blk = align_up((size_t)n_seq * w * esz);

@@ -111,7 +111,7 @@ int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
 template <typename T>
 bool pipelined_ok(const GemmArgs& a) {
   const int esz = (int)sizeof(T);
-  return a.K / (ROWB / esz) >= 3 && a.N % 8 == 0 && (a.ldc * esz) % 16 == 0 && a.bias != nullptr &&
+  return a.K / (ROWB / esz) >= 3 && a.N % 8 == 0 && (a.ldc * esz) % 16 == 0 && a.ldc % 4 == 0 && a.bias != nullptr &&
          ((uintptr_t)a.bias & 15) == 0 && (size_t)a.M * a.lda * esz < (1ull << 32) &&
          (size_t)a.N * a.ldw * esz < (1ull << 32);
 }
@@ -119,7 +119,7 @@ bool pipelined_ok(const GemmArgs& a) {
 template <typename T>
 int resolve_tile(int epi, const GemmArgs& a, int tile) {
   if (tile != 0) return tile;
-  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || ((epi == EPI_DGELU_T || epi == EPI_RESID_F32) && sizeof(T) == 4);
+  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || epi == EPI_RESID_F32 || (epi == EPI_DGELU_T && sizeof(T) == 4);
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
   return t256 >= 512 ? 2 : 1;
@@ -128,7 +128,7 @@ int resolve_tile(int epi, const GemmArgs& a, int tile) {
 // tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (BIAS_T / GELU_T only)
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
-  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || ((EPI == EPI_DGELU_T || EPI == EPI_RESID_F32) && sizeof(T) == 4);
+  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
     if constexpr (kHasPipelined) {

@@ -346,9 +346,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int RG = (BM + BN) / 8;
   constexpr int LPW = RG / NW;
-  constexpr bool kOutF32 = sizeof(T) == 4;
+  constexpr bool kOutF32 = sizeof(T) == 4 || EPI == EPI_RESID_F32;  // (the residual stream is fp32 in the bf16 mode too)
   constexpr bool kStaged = !kOutF32;                  // bf16 outputs: LDS-transposed, 16-byte full-line stores
-  using TOUT = T;
+  using TOUT = std::conditional_t<kOutF32, float, T>;
   constexpr int ROWP = TN * 2;                        // bytes per row of a wave's output patch (bf16)
   constexpr int CPR = ROWP / 16;                      // 16-byte chunks per patch row
   constexpr int PATCH = 16 * ROWP;                    // one 16-row pass of the wave tile
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
-  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || ((EPI == EPI_DGELU_T || EPI == EPI_RESID_F32) && sizeof(T) == 4), "epilogue");
+  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4), "epilogue");
   // the counted wait behind the epilogue stores needs LPW + NST to fit the 6-bit vmcnt; tilings with more stores per wave
   // (4 waves of 128x128) wait for everything at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;

@@ -42,17 +42,18 @@ def test_gemm_all_epilogues(M, N, K, tile, dtype):
     z = ref + bias.double()
     assert _rel(out, z * torch.sigmoid(1.702 * z)) < tol
     resid = _rand(M, N, seed=4)
-    if tile == 3:  # the persistent / pipelined kernel has the two store epilogues and, in fp32, the residual update
+    if tile == 3:  # the persistent / pipelined kernel has the two store epilogues and the residual update
+        # C(f32) += acc + bias in place: the bits of the plain kernels (a row does not depend on the kernel the batch
+        # selects); in fp32 also the bits of the bias epilogue followed by the fp32 add (what the fused add+LayerNorm did)
+        acc = resid.to(DEV).clone()
+        ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=3)
+        assert _rel(acc, resid.double() + z) < 2e-6
         if dtype == torch.float32:
-            # C += acc + bias in place: the bits of the bias epilogue followed by the fp32 add (what the fused
-            # add+LayerNorm did), and the bits of the plain kernels - a row does not depend on the kernel the batch selects
-            acc = resid.to(DEV).clone()
-            ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=3)
             assert torch.equal(acc, resid.to(DEV) + ops.gemm(ad, wd, bd, ops.EPI_BIAS_T, tile=3))
-            for other in (1, 2):
-                acc2 = resid.to(DEV).clone()
-                ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc2, tile=other)
-                assert torch.equal(acc2, acc)
+        for other in (1, 2):
+            acc2 = resid.to(DEV).clone()
+            ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc2, tile=other)
+            assert torch.equal(acc2, acc)
         return
     acc = resid.to(DEV).clone()
     ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc, tile=tile)
