@@ -33,7 +33,6 @@ namespace {
 
 constexpr float kNegInfS = -__builtin_inff();
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -67,17 +66,6 @@ __device__ __forceinline__ void split3x4(const f32x4& a, bf16x4& p1, bf16x4& p2,
   p2 = __builtin_bit_cast(bf16x4, u32x2{w.p2, x.p2});
   p3 = __builtin_bit_cast(bf16x4, u32x2{w.p3, x.p3});
 }
-// exp_neg_finite_f32 (common.h) on a pair: 2^(x log2 e) with the product's rounding error and the low half of log2 e
-// carried along
-__device__ __forceinline__ f32x2 exp_neg_finite_pair(const f32x2 x) {
-  constexpr float kHi = 1.4426950216293335f, kLo = 1.925963033500011e-08f, kLn2 = 0.6931471805599453f;
-  const f32x2 tt = x * kHi;
-  f32x2 rr = __builtin_elementwise_fma(x, f32x2{kHi, kHi}, -tt);
-  rr = __builtin_elementwise_fma(x, f32x2{kLo, kLo}, rr);
-  const f32x2 ee = {__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])};
-  return __builtin_elementwise_fma(ee, rr * kLn2, ee);
-}
-
 constexpr int NKT = 13, NKR = NKT * 16;      // 16-key tiles / rows per plane
 constexpr int PL = NKR * 128;                // bytes per plane
 constexpr int OFF_V = 3 * PL;

@@ -215,6 +215,18 @@ __device__ __forceinline__ float exp_neg_finite_f32(float x) {
   return __builtin_fmaf(e, r * 0.6931471805599453f, e);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// exp_neg_finite_f32 (common.h) on a pair: 2^(x log2 e) with the product's rounding error and the low half of log2 e
+// carried along
+__device__ __forceinline__ f32x2 exp_neg_finite_pair(const f32x2 x) {
+  constexpr float kHi = 1.4426950216293335f, kLo = 1.925963033500011e-08f, kLn2 = 0.6931471805599453f;
+  const f32x2 tt = x * kHi;
+  f32x2 rr = __builtin_elementwise_fma(x, f32x2{kHi, kHi}, -tt);
+  rr = __builtin_elementwise_fma(x, f32x2{kLo, kLo}, rr);
+  const f32x2 ee = {__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])};
+  return __builtin_elementwise_fma(ee, rr * kLn2, ee);
+}
+
 // max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} on v_permlane32_swap / v_permlane16_swap (no LDS round trip)
 __device__ __forceinline__ float max_over_lane_groups(float x) {
   const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
