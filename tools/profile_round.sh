@@ -23,9 +23,8 @@ export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
 # (fp32: the 2048 frames of a bench step run as 1663 + 385: 1663 frames = 1280 panels of 256 rows = whole rounds of the 256 CUs; bf16 512)
-# c_fc (+QuickGELU) has its own instantiation; c_proj shares one with out_proj (fp32: the residual epilogue, 2) or with QKV /
-# out_proj (bf16: the bias epilogue, 0) and is told apart by its duration window (fp32 @ 1663 frames in the main pass: c_proj
-# 11.4 ms, QKV 8.2, out_proj 3.0; bf16 @ 512: 0.40 / 0.32 / 0.12)
+# c_fc (+QuickGELU) has its own instantiation; c_proj shares one with out_proj (the residual epilogue, 2) and is told apart by
+# its duration window (fp32 @ 1663 frames in the main pass: c_proj 11.4 ms, out_proj 3.0; bf16 @ 512: 0.40 / 0.14)
 if [ "$prec" = fp32 ]; then
   steps=3; chunk=1663; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
@@ -33,7 +32,7 @@ if [ "$prec" = fp32 ]; then
 elif [ "$prec" = bf16 ]; then
   steps=5; chunk=512; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
-  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi0E|365|1e9|$rows|768|3072|bias"
+  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi2E|365|1e9|$rows|768|3072|bias_residual"
 else
   # fp32x6 = the split-fp32 leg of the fp32 bench run (the 2048 frames of a step run as 768 + 768 + 512; three-plane operands,
   # six bf16 products per fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation
