@@ -203,8 +203,8 @@ class CLIP(nn.Module):
         if self.chunk_frames > 0:
             return self.chunk_frames
         if self.precision in _SPLIT_GEMM:
-            return 512
-        return 998 if _PRECISIONS[self.precision] == _lib.PREC_F32 else 512  # order of the library's pass size (ViT-B/16)
+            return 768
+        return 2048  # order of the library's pass size (ViT-B/16; csrc/api.hip planned_chunk)
 
     def _encode_image_lanes(self, rt: "_Runtime", image: torch.Tensor, out: torch.Tensor, lanes: int) -> None:
         """Large batches (>= `lanes` chunks): contiguous slices of the frames go to `lanes` HIP streams (the caller's +

@@ -341,11 +341,9 @@ int gemm_x3(fc_handle* h, int epi, const void* A3, const void* W3, const float* 
   return launch_gemm_split3(epi, a, st);
 }
 
-// A pass qualifies for the three-plane GEMMs when its widest operand - the x3 MLP hidden rows, 32 w bytes each - stays
-// below the 4 GiB of the kernel's 32-bit row offsets and K spans the K-steps its prologue assumes.
-bool x3_pass_ok(int M, int w) {
-  return M > 0 && (size_t)M * (size_t)x3_row_elems(4 * w) * 2 < (1ull << 32) && w >= 64 && w % 32 == 0;
-}
+// A pass qualifies for the three-plane GEMMs when K spans the K-steps the kernel's prologue assumes (the operands are
+// addressed from 64-bit tile bases: no size limit on the pass).
+bool x3_pass_ok(int M, int w) { return M > 0 && w >= 64 && w % 32 == 0; }
 
 int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,
                   const float* fin_b, long pool_step, hipStream_t st, const TowerEntry& entry) {
@@ -408,31 +406,37 @@ int device_cus() {
   return cus;
 }
 
-// Items per pass of a tower over `n` items.  bf16: 512 frames (profiles/r01: the step does not react to the chunk size
-// there - when some CUs run out of tiles the others speed up, the chip being power- and bandwidth-limited).  fp32 is
+// Items per pass of a tower over `n` items.  bf16: up to 2048 frames (tile rounds do not matter there - when some CUs run
+// out of tiles the others speed up, the chip being power- and bandwidth-limited - but every pass pays its launches'
+// ramps: +2 % from 512 to 2048 frames).  fp32 is
 // MFMA-bound on every CU, so whole rounds of 256 x 256 tiles over the CUs matter: a pass whose number of 256-row panels is
 // a multiple of the CU count (ViT-B/16: 998 frames = 768 panels = 3, 9, 12 full rounds for the N = 768 / 2304 / 3072
 // GEMMs) runs its block GEMMs without a partial last round; 1024 frames would leave c_proj / out_proj at 9.23 rounds =
 // 92 %.  The pass size is chosen among those "whole round" sizes (and n itself) by the modelled number of tile rounds;
-// measured on the 2048-frame bench step: 433 pairs/s with 2 x 1024 frames, 450 with 998 + 998 + 52, 451 with the
-// planner's 1663 + 385 (1280 panels; the limit is the 32-bit operand offset of the 4w-wide buffer).
+// measured on the 2048-frame bench step: 433 pairs/s with 2 x 1024 frames, 450 with 998 + 998 + 52, 451 with 1663 + 385
+// (1280 panels: what the planner chose while a pass was bounded by 32-bit operand offsets, 1774 frames) - and, since the
+// GEMM addresses its activation rows from a 64-bit tile base, ONE pass of 2048 frames: the same modelled rounds (the
+// remainder of the last round runs as half tiles, gemm.hip), none of the second pass's launches - 464 -> 474 pairs/s.
 int planned_chunk(const fc_handle* h, int tower, int n) {
   const fc_config& c = h->cfg;
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
-  if (c.precision != FC_PREC_F32) return 512;
+  if (c.precision != FC_PREC_F32) return 2048;  // (bench step, pairs/s: passes of 512 frames 3003, 1024: 3023, 2048: 3066)
   const long T = h->vtokens(), w = c.vision_width, cus = device_cus();
   if (h->split()) {
     // bf16-pipe GEMMs: no whole-round planning, as in bf16 mode.  Measured on the 2048-frame bench step (pairs/s, share of the
     // bf16 peak of the split GEMMs): passes of 256 frames 594 / 0.47, 384: 613 / 0.49, 512: 624 / 0.50, 600: 626, 700: 632,
     // 768: 633-635 / 0.51, 850: 626, 886: 620; the planner's whole-round size (665 frames = 512 panels: 18 / 6 / 24 / 6 whole
     // rounds) is the WORST of the large ones, 607 / 0.47 - with every workgroup of an XCD ending its tiles at the same moment
-    // the epilogue stores and the first DMA of the next tiles arrive in bursts.  The x3 MLP rows of a pass (32 w bytes each)
-    // must stay below the 4 GiB of the kernel's 32-bit row offsets (887 frames for ViT-B/16).
-    const long max3 = (long)(((1LL << 32) - 1) / (2LL * x3_row_elems(4L * w)) / T);
-    return (int)std::max(1L, std::min(768L, max3));
+    // the epilogue stores and the first DMA of the next tiles arrive in bursts.  Larger passes (possible since the kernel
+    // addresses its activation rows from 64-bit tile bases) do not help here: 768: 704, 1024: 691, 2048 (one pass): 697.
+    static const long split_pass = [] { const char* e = getenv("FITCLIP_SPLIT_PASS_FRAMES"); return e ? std::max(1L, atol(e)) : 768L; }();  // (A/B)
+    return (int)split_pass;
   }
-  const long max_frames = std::max(1L, (long)((1LL << 32) - 1) / (16 * w) / T);  // 32-bit operand offsets of the 4w-wide buffer
+  // (the pipelined GEMM addresses its activation rows from a 64-bit tile base; what bounds a pass is the workspace it needs -
+  // 3.6 MB per ViT-B/16 frame - so: at most 4096 frames, FITCLIP_MAX_PASS_FRAMES overrides for A/B runs)
+  static const long pass_cap = [] { const char* e = getenv("FITCLIP_MAX_PASS_FRAMES"); return e ? std::max(1L, atol(e)) : 4096L; }();
+  const long max_frames = pass_cap;
   auto rounds = [&](long frames) {  // tile rounds x K-steps of the four block GEMMs of one pass
     const long panels = (frames * T + 255) / 256;
     const long shapes[4][2] = {{3 * w, w}, {w, w}, {4 * w, w}, {w, 4 * w}};

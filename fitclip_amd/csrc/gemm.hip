@@ -112,7 +112,7 @@ template <typename T>
 bool pipelined_ok(const GemmArgs& a) {
   const int esz = (int)sizeof(T);
   return a.K / (ROWB / esz) >= 3 && a.N % 8 == 0 && (a.ldc * esz) % 16 == 0 && a.ldc % 4 == 0 && a.bias != nullptr &&
-         ((uintptr_t)a.bias & 15) == 0 && (size_t)a.M * a.lda * esz < (1ull << 32) &&
+         ((uintptr_t)a.bias & 15) == 0 && (size_t)256 * a.lda * esz < (1ull << 32) &&
          (size_t)a.N * a.ldw * esz < (1ull << 32);
 }
 

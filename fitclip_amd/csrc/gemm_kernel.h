@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   int t = t_begin + pos;
   if (t >= t_end) return;
 
-  // per-lane staging sources as 32-bit byte offsets from the two (scalar) base pointers: operands are < 4 GiB
+  // per-lane staging sources as 32-bit byte offsets from two (scalar) base pointers: the weight is < 4 GiB, the activations
+  // are addressed from the first row of the current tile
   constexpr int LPA = BM / 8 / NW, LPB = BN / 8 / NW;  // LDS-DMA instructions per wave per stage for A / W
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must divide over the waves");
   const int rin = lane >> 3, pc = lane & 7;
@@ -408,6 +409,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   static_assert((NW * 4) % 8 == 0, "swizzle term must not depend on i");
   const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
   unsigned offA[LPA], offB[LPB];
+  const char* a_tile = reinterpret_cast<const char*>(g.A);  // 64-bit base of the current tile's first activation row (scalar)
   const int nk = g.K / BKE;
   // K-tiles of a tile are visited in the rotated order rot, rot+1, ..., nk-1, 0, ..., rot-1 with rot = (first column / 256) mod nk:
   // the workgroups that share an activation panel then read different K-slices (different L2 channels) at any moment
@@ -420,11 +422,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     m0 = tm * BM;
     n0 = tn * BN;
     if constexpr (ROT == 1) rot = (n0 >> 8) % nk;  // a function of the output column block only
+    // activation rows: a 64-bit tile base + 32-bit offsets inside the tile (the 4w-wide MLP rows of a 2048-frame fp32 pass are
+    // 5 GB; the weight stays below 4 GiB)
+    const int mb = ABL == 2 ? 0 : m0;
+    a_tile = reinterpret_cast<const char*>(g.A) + (size_t)mb * ((size_t)g.lda * sizeof(T));
 #pragma unroll
     for (int i = 0; i < LPA; ++i) {
-      const int row = (wave + i * NW) * 8 + rin;
-      const int gr = min((ABL == 2 ? 0 : m0) + row, g.M - 1);
-      offA[i] = (unsigned)gr * (unsigned)(g.lda * (int)sizeof(T)) + swz;
+      const int row = min((wave + i * NW) * 8 + rin, g.M - 1 - mb);
+      offA[i] = (unsigned)row * (unsigned)(g.lda * (int)sizeof(T)) + swz;
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[i] + (unsigned)kt * ROWB)),
+          (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * ROWB)),
           (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     char* dst = smem + stage * STAGE + wave * 1024;
     if constexpr (idx < LPA)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[idx] + (unsigned)kt * ROWB)),
+          (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * ROWB)),
           (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
     else
       __builtin_amdgcn_global_load_lds(

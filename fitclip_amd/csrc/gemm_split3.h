@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   // activation panel read different lines at any moment, and a row's result does not depend on the rows around it
   int rot = 0;
   unsigned offA[LPA], offB[LPB];
+  const char* a_tile = reinterpret_cast<const char*>(g.A);  // 64-bit base of the current tile's first activation row (scalar)
   // piece i of this wave covers chunks (wave + 8 i) * 64 + lane of the [rows][6 chunks] image of its operand tile
   auto tile_sources = [&](int tile, int& m0, int& n0) {
     const int tm = mp0 + tile / tnn, tn = tn0 + tile % tnn;
@@ -102,10 +103,13 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
     // with stride 0 / 1 / 2 / 3, c_fc (with its N split) 3.6 GB with 1 against 4.2 with 2.  Lockstep groups of 2 - 4 column
     // tiles (g.P, lab only) change nothing.  g.nblock - 1 overrides the stride in the lab.
     rot = ((tn / (g.P > 0 ? g.P : 1)) * (g.nblock > 0 ? g.nblock - 1 : 1)) % nk;
+    // activation rows: a 64-bit tile base + 32-bit offsets inside the tile (the x3 MLP rows of a pass may exceed 4 GiB)
+    const int mb = ABL == 2 ? 0 : m0;
+    a_tile = reinterpret_cast<const char*>(g.A) + (size_t)mb * lda_b;
 #pragma unroll
     for (int i = 0; i < LPA; ++i) {
       const int c6 = (wave + i * NW) * 64 + lane, row = c6 / 6, c = c6 - row * 6;
-      const int gr = min((ABL == 2 ? 0 : m0) + row, g.M - 1);
+      const int gr = min(row, g.M - 1 - mb);
       offA[i] = (unsigned)gr * lda_b + (unsigned)((c >> 1) * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4));
     }
 #pragma unroll
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[i] + (unsigned)kt * X3_GROUP_BYTES)),
+          (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * X3_GROUP_BYTES)),
           (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
     char* dst = smem + stage_off + wave * 1024;
     if constexpr (idx < LPA)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.A) + (offA[idx] + (unsigned)kt * X3_GROUP_BYTES)),
+          (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * X3_GROUP_BYTES)),
           (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
     else
       __builtin_amdgcn_global_load_lds(

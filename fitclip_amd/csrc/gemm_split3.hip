@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) split3_rows_kernel(const float* __restric
 
 bool gemm_split3_ok(const GemmArgs& a) {
   return a.M > 0 && a.N > 0 && a.K >= 64 && a.K % 32 == 0 && a.N % 32 == 0 && a.bias != nullptr &&
-         ((uintptr_t)a.bias & 15) == 0 && (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);
+         ((uintptr_t)a.bias & 15) == 0 && (size_t)256 * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);
 }
 
 int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream) {
@@ -80,8 +80,8 @@ int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream) {
   if (((uintptr_t)a.A | (uintptr_t)a.W) & 127 || ((uintptr_t)a.C & 15))
     return fail(FC_EINVAL, "gemm_split3: operands must be 128-byte aligned (x3 rows are made of whole lines)");
   if (!a.bias || ((uintptr_t)a.bias & 15)) return fail(FC_EINVAL, "gemm_split3: bias missing or unaligned");
-  if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32))
-    return fail(FC_EINVAL, "gemm_split3: an operand exceeds the 4 GiB of the kernel's 32-bit row offsets");
+  if ((size_t)256 * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32))
+    return fail(FC_EINVAL, "gemm_split3: the weight (or a 256-row tile of the activations) exceeds the 4 GiB of the kernel's 32-bit row offsets");
   switch (epilogue) {
     case EPI_BIAS_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split3: ldc=%d", a.ldc);

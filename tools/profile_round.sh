@@ -22,11 +22,11 @@ cd /tmp && export TMPDIR=/tmp
 export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
-# (fp32: the 2048 frames of a bench step run as 1663 + 385: 1663 frames = 1280 panels of 256 rows = whole rounds of the 256 CUs; bf16 512)
+# (fp32: the 2048 frames of a bench step run as ONE pass; bf16 512)
 # c_fc (+QuickGELU) has its own instantiation; c_proj shares one with out_proj (the residual epilogue, 2) and is told apart by
-# its duration window (fp32 @ 1663 frames in the main pass: c_proj 11.4 ms, out_proj 3.0; bf16 @ 512: 0.40 / 0.14)
+# its duration window (fp32 @ 2048 frames: c_proj 13.2 ms, out_proj 3.5; bf16 @ 512: 0.40 / 0.14)
 if [ "$prec" = fp32 ]; then
-  steps=3; chunk=1663; rows=$((chunk * 197))
+  steps=3; chunk=2048; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 2,|9800|1e9|$rows|768|3072|bias_residual"
 elif [ "$prec" = bf16 ]; then

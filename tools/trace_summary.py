@@ -58,7 +58,8 @@ def main():
         labelled.append([label, dur])
     # visual-tower launches of the pipelined GEMMs run for > 80 us at chunk >= 256 frames; the text tower's for < 60 us
     # (fp32: visual >= 900 us, text <= 350 us)
-    # (fp32 bench step: passes of 1663 + 385 frames; the shortest visual launch, out_proj of the short pass, runs 0.7 ms)
+    # (fp32 bench step: one pass of 2048 frames; the shortest visual launch, out_proj, runs 3.5 ms - or 0.6 ms in the short
+    # pass of a step that is split, e.g. 1663 + 385 under FITCLIP_MAX_PASS_FRAMES=1774)
     cut = 500.0 if fp32 else 70.0
     cut_small = 100.0 if fp32 else 40.0
     seq = seq2 = 0
