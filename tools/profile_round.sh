@@ -22,17 +22,17 @@ cd /tmp && export TMPDIR=/tmp
 export FITCLIP_OVERLAP_TEXT=0
 # kernel-name substring of the dominant kernel (c_fc + QuickGELU, pipelined 256x256) as rocprofv3 prints it: demangled for
 # float, still mangled for __bf16 instantiations
-# (fp32: the 2048 frames of a bench step run as ONE pass; bf16 512)
+# (fp32 and bf16: the 2048 frames of a bench step run as ONE pass)
 # c_fc (+QuickGELU) has its own instantiation; c_proj shares one with out_proj (the residual epilogue, 2) and is told apart by
-# its duration window (fp32 @ 2048 frames: c_proj 13.2 ms, out_proj 3.5; bf16 @ 512: 0.40 / 0.14)
+# its duration window (fp32 @ 2048 frames: c_proj 13.2 ms, out_proj 3.5; bf16 @ 2048: 1.8 / 0.55)
 if [ "$prec" = fp32 ]; then
   steps=3; chunk=2048; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 2,|9800|1e9|$rows|768|3072|bias_residual"
 elif [ "$prec" = bf16 ]; then
-  steps=5; chunk=512; rows=$((chunk * 197))
-  spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|250|1e9|$rows|3072|768|bias_quickgelu"
-  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi2E|365|1e9|$rows|768|3072|bias_residual"
+  steps=5; chunk=2048; rows=$((chunk * 197))
+  spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|1000|1e9|$rows|3072|768|bias_quickgelu"
+  spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi2E|1000|1e9|$rows|768|3072|bias_residual"
 else
   # fp32x6 = the split-fp32 leg of the fp32 bench run (the 2048 frames of a step run as 768 + 768 + 512; three-plane operands,
   # six bf16 products per fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation
