@@ -187,7 +187,7 @@ FC_API int fc_split3(const float* in, int64_t ld_in, void* out, int64_t ld_out, 
  * accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-26 per product, at the bf16 matrix cores'
  * rate.  epilogue 6: C fp32 [M, N] = acc + bias (ldc floats); epilogue 7: C x3 rows [M, 4 N] = planes(QuickGELU(acc + bias))
  * (ldc bf16 positions), the next GEMM's A operand; epilogue 8: C fp32 [M, N] += acc + bias, in place (the residual update
- * x = x + proj(..) of slip.py:382-385 in the projection's epilogue).  K % 32 == 0, K >= 64, N % 32 == 0; the weight (and any 256 rows of A3) below 4 GiB. */
+ * x = x + proj(..) of slip.py:382-385 in the projection's epilogue).  K % 32 == 0, K >= 64, N % 32 == 0; operands below 4 GiB. */
 FC_API int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, const float* bias, void* C, int32_t M, int32_t N,
                    int32_t K, int32_t lda, int32_t ldw, int32_t ldc, fc_stream stream);
 
