@@ -4,6 +4,7 @@
 // For every (shape, variant): checks 8192 sampled outputs against a naive fp32 dot product of the same bf16 operands,
 // then times `reps` back-to-back launches with hipEvents on random (never zero-filled) operands.
 #include "gemm_kernel.h"
+#include "gemm_wreg_lab.h"
 #include "gemm_deep_lab.h"
 #include "gemm_ring_lab.h"
 
@@ -101,6 +102,19 @@ void launch_pipelined(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles < cap ? tiles : cap), dim3(WM * WN * 64), lds, st, a);
 }
 
+template <int EPI, int ABL, int SCHED = 0>
+void launch_wreg(const GemmArgs& a, hipStream_t st) {  // a.aux: the weight in fragment order (pack_w_frag_kernel)
+  constexpr int lds = 2 * 512 * ROWB + 8 * 2048 + 2048;
+  auto kern = gemm_wreg_kernel<256, 256, 2, 4, EPI, ABL, 1, SCHED>;
+  static bool configured = false;
+  if (!configured) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
+}
+
 template <int EPI, int ABL>
 void launch_deep(const GemmArgs& a, hipStream_t st) {
   constexpr int lds = 4 * 512 * 64 + 8 * 2048 + 2048;
@@ -153,8 +167,11 @@ int main(int argc, char** argv) {
     fill_kernel<<<2048, 256, 0, st>>>(A, (size_t)M * sh.K, 1u, 1.0f);
     fill_kernel<<<2048, 256, 0, st>>>(W, (size_t)sh.N * sh.K, 2u, 2.0f / sqrtf((float)sh.K));
     fill_f32_kernel<<<64, 256, 0, st>>>(bias, sh.N, 3u);
+    bf16x8* Wp;
+    HIP_OK(hipMalloc(&Wp, (size_t)((sh.N + 255) / 256) * 256 * sh.K * 2));
+    pack_w_frag_kernel<<<1024, 256, 0, st>>>(W, Wp, sh.N, sh.K, sh.K);
     GemmArgs a{};
-    a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
+    a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = reinterpret_cast<const float*>(Wp); a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K; a.lda = sh.K; a.ldw = sh.K; a.ldc = sh.N; a.P = 0;
     for (const Variant& v : variants) {
       HIP_OK(hipMemsetAsync(C, 0, (size_t)M * sh.N * 2, st));
@@ -192,6 +209,7 @@ int main(int argc, char** argv) {
              sh.K, v.name, ms, tf, tf / 2500.0, worst, worst < 2e-2f ? "ok" : "WRONG(expected for ablations)");
       fflush(stdout);
     }
+    HIP_OK(hipFree(Wp));
     HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(C)); HIP_OK(hipFree(bias)); HIP_OK(hipFree(err));
   }
   return 0;
