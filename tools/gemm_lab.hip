@@ -115,6 +115,25 @@ void launch_wreg(const GemmArgs& a, hipStream_t st) {  // a.aux: the weight in f
   hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
 }
 
+// 256 x 128 workgroup tile, 8 waves of 64 x 64: 64 accumulator registers, room for two register sets of weight fragments.
+// a.bias .. unchanged; a.P carries the SECOND packed weight (128-column tiles) as an offset in bytes from a.aux (lab hack)
+template <int EPI, int ABL>
+void launch_wreg_narrow(const GemmArgs& a0, hipStream_t st) {
+  constexpr int BM = 256, BN = 128, WM = 4, WN = 2;
+  constexpr int lds = 2 * (BM + BN) * ROWB + 8 * 2048 + 2048;
+  auto kern = gemm_wreg_kernel<BM, BN, WM, WN, EPI, ABL, 1, 0>;
+  static bool configured = false;
+  if (!configured) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  GemmArgs a = a0;
+  a.aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.aux) + (size_t)a0.gR * 1024);  // second pack, KiB offset
+  a.gR = 0;
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
+}
+
 template <int EPI, int ABL>
 void launch_deep(const GemmArgs& a, hipStream_t st) {
   constexpr int lds = 4 * 512 * 64 + 8 * 2048 + 2048;
@@ -168,11 +187,14 @@ int main(int argc, char** argv) {
     fill_kernel<<<2048, 256, 0, st>>>(W, (size_t)sh.N * sh.K, 2u, 2.0f / sqrtf((float)sh.K));
     fill_f32_kernel<<<64, 256, 0, st>>>(bias, sh.N, 3u);
     bf16x8* Wp;
-    HIP_OK(hipMalloc(&Wp, (size_t)((sh.N + 255) / 256) * 256 * sh.K * 2));
-    pack_w_frag_kernel<<<1024, 256, 0, st>>>(W, Wp, sh.N, sh.K, sh.K);
+    const size_t pack_bytes = (size_t)((sh.N + 255) / 256) * 256 * sh.K * 2;  // (a multiple of 1 KiB)
+    HIP_OK(hipMalloc(&Wp, 2 * pack_bytes));
+    pack_w_frag_kernel<<<1024, 256, 0, st>>>(W, Wp, sh.N, sh.K, sh.K, 256);
+    pack_w_frag_kernel<<<1024, 256, 0, st>>>(W, reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Wp) + pack_bytes), sh.N, sh.K, sh.K, 128);
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = reinterpret_cast<const float*>(Wp); a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K; a.lda = sh.K; a.ldw = sh.K; a.ldc = sh.N; a.P = 0;
+    a.gR = (int)(pack_bytes / 1024);  // (lab: where the 128-column pack starts; the kernels under test ignore gR)
     for (const Variant& v : variants) {
       HIP_OK(hipMemsetAsync(C, 0, (size_t)M * sh.N * 2, st));
       v.launch(a, st);

@@ -15,14 +15,17 @@ namespace {
 
 // W [N, K] bf16 row-major -> fragment order: ((((tn * nk + kt) * 4 + wn) * 2 + s) * 4 + j) * 64 + lane  x 16 bytes, lane (r, q)
 // = row tn * 256 + wn * 64 + j * 16 + r, k = kt * 64 + s * 32 + 8 q .. + 7
-__global__ void pack_w_frag_kernel(const bf16* __restrict__ W, bf16x8* __restrict__ out, int N, int K, int ldw) {
-  const int nk = K / 64;
-  const size_t total = (size_t)((N + 255) / 256) * nk * 4 * 2 * 4 * 64;
+// (tile of BNc columns = WNc wave columns of 64: FN = 4 fragments each)
+__global__ void pack_w_frag_kernel(const bf16* __restrict__ W, bf16x8* __restrict__ out, int N, int K, int ldw, int BNc = 256) {
+  const int nk = K / 64, WNc = BNc / 64;
+  const size_t total = (size_t)((N + BNc - 1) / BNc) * nk * WNc * 2 * 4 * 64;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63), j = (int)((i >> 6) & 3), s = (int)((i >> 8) & 1), wn = (int)((i >> 9) & 3);
-    const size_t rest = i >> 11;
+    const int lane = (int)(i & 63), j = (int)((i >> 6) & 3), s = (int)((i >> 8) & 1);
+    size_t rest = i >> 9;
+    const int wn = (int)(rest % WNc);
+    rest /= WNc;
     const int kt = (int)(rest % nk), tn = (int)(rest / nk);
-    const int row = tn * 256 + wn * 64 + j * 16 + (lane & 15), k = kt * 64 + s * 32 + (lane >> 4) * 8;
+    const int row = tn * BNc + wn * 64 + j * 16 + (lane & 15), k = kt * 64 + s * 32 + (lane >> 4) * 8;
     bf16x8 v = {};
     if (row < N) v = *reinterpret_cast<const bf16x8*>(W + (size_t)row * ldw + k);
     out[i] = v;
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_wreg_kernel(const GemmArgs 
   // group u of the NEXT K-step (the stage it lands in was released by the hand-over barrier that precedes that step).
   // Each piece blocks its wave's issue port for ~100 cycles, and right after the barrier the two waves of a SIMD would
   // both be in that burst, with nobody feeding the matrix pipe.
-  static_assert(SCHED == 0 || LPW == 8, "piece schedules are written for 8 pieces per wave");
+  static_assert(SCHED == 0 || LPW == 8 || LPW == 6, "piece schedules are written for 8 pieces per wave");
   auto handover_pieces = [&](int stage, int kt) {
     static_for<LPW>([&](auto I) {
       if constexpr (piece_slot(SCHED, decltype(I)::value) < 0) stage_piece(stage, kt, I);
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_wreg_kernel(const GemmArgs 
     constexpr int par = decltype(PAR)::value, sub = decltype(SUB)::value;
     kt += rotw;
     if (kt >= nk) kt -= nk;
-    const char* src = wp + ((size_t)((n0w >> 8) * nk + kt) * WN + wn) * (2 * FN * 1024) + lane * 16 + sub * FN * 1024;
+    const char* src = wp + ((size_t)((n0w / BN) * nk + kt) * WN + wn) * (2 * FN * 1024) + lane * 16 + sub * FN * 1024;
 #pragma unroll
     for (int j = 0; j < FN; ++j) wreg[par][sub][j] = *reinterpret_cast<const FragT*>(src + j * 1024);
   };
