@@ -202,7 +202,7 @@ def load_traffic(precision, shape, epilogue):
     the ones in this tree is refused."""
     from fitclip_amd.build import source_fingerprint
     fp = source_fingerprint()
-    for name in (f"traffic_r03_{precision}.json", f"traffic_r02_{precision}.json"):
+    for name in (f"traffic_r04_{precision}.json", f"traffic_r03_{precision}.json", f"traffic_r02_{precision}.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -507,6 +507,7 @@ class Legs:
 
 CONFIG_DEFAULTS = {  # BASELINE.json `configs`: index, clips, frames, scaling
     "c2": {"baseline_index": 1, "frames": 8, "scaling": "weak"},
+    "c3": {"baseline_index": 2, "total_clips": 4096, "frames": 4, "scaling": "strong", "eval_batch": 32},
     "c4": {"baseline_index": 3, "total_clips": 8192, "frames": 16, "scaling": "strong", "eval_batch": 128},
     "c5": {"baseline_index": 4, "total_clips": 512, "frames": 8, "scaling": "strong"},
 }
@@ -557,17 +558,156 @@ def run_kd_config(sd, dims, args, shards, device, backend):
             "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
+def graph_leg(enc, module, video, ids, bs, device, reps=20):
+    """The reference-shaped call (one eval batch: both towers, pooling, the batch's score matrix, ranks) captured ONCE into a
+    hipGraph and replayed, next to the same call launched eagerly: bitwise equality of every output and ms per call.  What the
+    header promises ("all functions may be captured into a hipGraph") exercised on the production path: ~330 kernel launches
+    on two streams (the text tower runs beside the visual tower) become one graph launch."""
+    from fitclip_amd import ops
+    v, t = video[:bs].contiguous(), {"input_ids": ids[:bs].contiguous()}
+
+    def call():
+        ev, et = enc(video=v, text=t)
+        scores = ops.similarity(et, ev)
+        return ev, et, scores, ops.ranks(scores)
+
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager = call()  # warm-up on the capture stream: dynamic-LDS attributes, workspaces, side streams exist afterwards
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            captured = call()
+        for o in captured:
+            o.zero_()  # the replay must rewrite every output
+        graph.replay()
+        side.synchronize()
+        equal = all(torch.equal(a, b) for a, b in zip(eager, captured))
+
+        def timed(fn):
+            fn()
+            side.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            side.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        eager_ms, replay_ms = timed(call), timed(graph.replay)
+    torch.cuda.current_stream().wait_stream(side)
+    del graph
+    return {"call": f"encoder(video[{bs}x{video.shape[1]}], text[{bs}]) + T@V^T + ranks", "eager_ms": round(eager_ms, 3),
+            "replay_ms": round(replay_ms, 3), "bitwise_equal_to_eager": bool(equal),
+            "note": "one capture on a side stream (torch.cuda.CUDAGraph = hipStreamBeginCapture / hipGraphLaunch), replayed; "
+                    "both towers, pooling, scoring and ranks are library launches on the captured streams"}
+
+
+def run_wise_config(dims, args, shards, device, backend):
+    """`--config c3` (BASELINE configs[2]): `encoder=wise` - theta = 0.5 CLIP + 0.5 student, blended on the device by `fc_wise`
+    (aligner/wise.py:10-23, config/encoder/wise.yaml:6-9) - evaluated at the WebVid-val shape, `total_clips` clips x 4 frames +
+    one caption each, through the evaluate loop of the reference (`TextVideoRetrievalModule`: aligner/text_video_retrieval.py:
+    40-83) in eval batches of 32 clips = 128 frames per encoder call (aligner/data/video_data_module.py:32,
+    aligner/encoder/clip_video_text_encoder.py:69).  One step = one epoch over this rank's shard: per batch both towers, the
+    batch's score matrix and NCE loss; at the end ONE all-gather of the embeddings, T @ V^T, ranks, R@k / MedR."""
+    from fitclip_amd import distributed as D
+    from fitclip_amd import synth
+    from fitclip_amd.__main__ import instantiate, load_encoder_config
+    from fitclip_amd.retrieval import TextVideoRetrievalModule
+    n, frames, bs = shards.n_local, args.frames, shards.eval_batch or shards.n_local
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc = instantiate(load_encoder_config("wise", {"precision": "fp32", "num_frames": frames, "weight_for_2": 0.5}, device)).to(device)
+    enc.num_frames = frames
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    video = fill_video(n, frames, dims.image_resolution, seed=1000 + shards.rank, device=device)
+    ids = torch.from_numpy(synth.make_text(n, dims, seed=42, first_text=shards.offset)).to(device)
+    module = TextVideoRetrievalModule(enc, init_temperature=0.015, n_total=shards.n_total)
+
+    def epoch(batch=bs):
+        with torch.inference_mode():
+            for s in range(0, n, batch):
+                module.validation_step_end(module.validation_step(
+                    {"video": video[s:s + batch], "text": {"input_ids": ids[s:s + batch]}, "video_id": list(range(s, min(n, s + batch)))}))
+            return module.validation_epoch_end()
+
+    for _ in range(max(1, args.warmup)):
+        epoch()
+    elapsed, metrics = timed_steps(epoch, args.steps, device, backend)
+    peak = PEAK_TFLOPS["fp32"]
+    flops = max(shards.counts) * (frames * GF_PER_FRAME + GF_PER_TEXT)
+    out = {"value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "metrics": metrics, "encoder_build_s": round(build_s, 2),
+           "roofline_whole_path": {"achieved": round(flops * args.steps / elapsed / 1e12, 2), "unit": "TFLOP/s",
+                                   "frac": round(flops * args.steps / elapsed / 1e12 / peak, 4)}}
+    # untimed: one epoch with hipEvent pairs around every GEMM / attention / LayerNorm launch of the towers (text tower on the
+    # visual tower's stream, so that a duration describes a kernel that owns the chip)
+    enc.model.profile(65536)
+    enc.model.profile_reset()
+    overlap, enc.overlap_text = enc.overlap_text, False
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    epoch()
+    torch.cuda.synchronize()
+    inst_s = time.perf_counter() - t1
+    enc.overlap_text = overlap
+    records = enc.model.profile_records()
+    enc.model.profile(0)
+    by_kernel, other = aggregate(records)
+    (epi, N, K, M, tile), (ms, cnt, kflops) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+    gemm_ms, gemm_flops = sum(v[0] for v in by_kernel.values()), sum(v[2] for v in by_kernel.values())
+    hp, ht = (None, None)
+    if tile == 3:
+        from fitclip_amd import ops
+        hp, ht = ops.gemm_plan(M, N, K)
+    kname = {1: "gemm_kernel<128x128>", 2: "gemm_kernel<256x256>", 3: "gemm_pipelined_kernel<256x256>"}.get(tile, "gemm")
+    traffic, traffic_note = load_traffic("fp32", (M, N, K), EPI_NAMES[epi])
+    out["roofline"] = {"bound": "mfma", "kernel": f"{kname}<fp32,{EPI_NAMES[epi]}> M={M} N={N} K={K}",
+                       "achieved": round(kflops / (ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                       "frac": round(kflops / (ms * 1e-3) / 1e12 / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+                       "launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "flops_per_launch": kflops / cnt,
+                       "row_cut": None if hp is None else {"head_panels_256": hp, "tail_tile_rows": 64 * ht},
+                       "timing": "hipEvent pairs in one instrumented epoch after the timed region",
+                       "share_of_step_time": round(ms / (inst_s * 1e3), 4)}
+    out["roofline_all_gemms"] = {"achieved": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                 "frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                                 "share_of_step_time": round(gemm_ms / (inst_s * 1e3), 4)}
+    out["time_split"] = {**{k: {"share_of_step_time": round(v[0] / (inst_s * 1e3), 4), "launches": v[1],
+                                "avg_launch_ms": round(v[0] / max(1, v[1]), 4)} for k, v in other.items()},
+                         "gemm": {"share_of_step_time": out["roofline_all_gemms"]["share_of_step_time"]},
+                         "per_gemm": [{"epilogue": EPI_NAMES.get(k[0], k[0]), "N": k[1], "K": k[2], "M": k[3], "tile": k[4],
+                                       "launches": v[1], "avg_launch_ms": round(v[0] / v[1], 4),
+                                       "frac_of_peak": round(v[2] / (v[0] * 1e-3) / 1e12 / peak, 4)}
+                                      for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:8]],
+                         "instrumented_step_ms": round(inst_s * 1e3, 3)}
+    if shards.rank == 0 and len(shards.counts) == 1:
+        if n >= 256 and bs != 256:  # the second key: the same epoch in eval batches of 256 clips (1024 frames per call)
+            epoch(256)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                epoch(256)
+            torch.cuda.synchronize()
+            e256 = (time.perf_counter() - t2) / args.steps
+            out["eval_batch_256"] = {"value": round(n / e256, 2), "ms_per_step": round(e256 * 1e3, 3),
+                                     "frac_of_fp32_mfma_peak": round(flops / e256 / 1e12 / peak, 4)}
+        out["hipgraph"] = graph_leg(enc, module, video, ids, min(bs, n), device)
+    return out, enc, video, ids
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIG_DEFAULTS),
-                    help="c2 = BASELINE configs[1] (default; weak scaling, 256 clips x 8 frames per GPU); c4 = configs[3] "
+                    help="c2 = BASELINE configs[1] (default; weak scaling, 256 clips x 8 frames per GPU); c3 = configs[2] (encoder=wise, "
+                         "4096 clips x 4 frames through the evaluate loop in eval batches of 32 clips; strong); c4 = configs[3] "
                          "(8192 clips x 16 frames in total, sharded; strong); c5 = configs[4] (512 x 8 teacher+student KD "
                          "training step in total, sharded; strong)")
-    ap.add_argument("--total-clips", type=int, default=None, help="c4 / c5: clips over ALL ranks (default 8192 / 512)")
-    ap.add_argument("--eval-batch", type=int, default=None, help="c4: clips per encoder call (default 128)")
+    ap.add_argument("--total-clips", type=int, default=None, help="c3 / c4 / c5: clips over ALL ranks (default 4096 / 8192 / 512)")
+    ap.add_argument("--eval-batch", type=int, default=None, help="c3 / c4: clips per encoder call (default 32 / 128)")
     ap.add_argument("--all-legs", action="store_true",
                     help="with more than one rank, also run the secondary legs (bf16_mode, fp32_split_mode); default: headline only")
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"],
@@ -577,7 +717,7 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=256, help="c2: clips (= captions) per GPU per step")
     ap.add_argument("--frames", type=int, default=None, help="frames per clip (default 8; c4: 16)")
     ap.add_argument("--chunk-frames", type=int, default=0)
-    ap.add_argument("--split-chunk-frames", type=int, default=0, help="frames per pass of the fp32_split_mode leg (0 = the library's 512)")
+    ap.add_argument("--split-chunk-frames", type=int, default=0, help="frames per pass of the fp32_split_mode leg (0 = the library's default, 768)")
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -665,6 +805,49 @@ def main() -> None:
                              "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
                              "collectives": collectives},
                   "roofline": kd["roofline"], "losses": kd["losses"], "peak_memory_gb": kd["peak_memory_gb"]}
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if grouped:
+            dist.destroy_process_group()
+        return
+
+    if args.config == "c3":
+        w3, enc3, video3, ids3 = run_wise_config(dims, args, shards, device, args.backend)
+        result = {**base, "metric": "video-text pairs/sec through command=evaluate, encoder=wise (4-frame 224^2, 77-tok)",
+                  "value": w3["value"], "ms_per_step": w3["ms_per_step"],
+                  "config": {"workload": f"encoder=wise (0.5 CLIP + 0.5 student, ViT-B/16, blended on the device), WebVid-val shape: "
+                                         f"{n_total} clips x {args.frames} frames x 224^2 + {n_total} x 77-token texts in total "
+                                         f"through TextVideoRetrievalModule in eval batches of {shards.eval_batch or n_local} clips "
+                                         f"({(shards.eval_batch or n_local) * args.frames} frames per encoder call) -> per-batch NCE "
+                                         f"loss -> one all-gather -> T@V^T -> R@k / MedR (BASELINE configs[2])",
+                             "total_clips": n_total, "frames": args.frames, "eval_batch": shards.eval_batch or n_local,
+                             "sharding": sharding, "weights": "random init (seed 42) CLIP, student = CLIP perturbed by 5 %, "
+                                                              "weight_for_2 = 0.5",
+                             "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
+                             "collectives": collectives, "encoder_build_s (two models + WiSE blend)": w3["encoder_build_s"]},
+                  **{k: w3[k] for k in ("roofline", "roofline_all_gemms", "roofline_whole_path", "time_split", "eval_batch_256",
+                                        "hipgraph") if k in w3},
+                  "retrieval": {**{k: v for k, v in w3["metrics"].items()}, "n": n_total, "path": "device, fp32",
+                                "note": "purely random towers: chance-level recall; parity is in cpu_baseline"}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import clip_oracle as O
+            cores = min(host_cores(), 64)
+            torch.set_num_threads(cores)
+            k = min(args.cpu_sample_clips, n_local)
+            sd_t = {kk: vv.detach().float().cpu() for kk, vv in enc3.model.state_dict().items()}
+            with torch.inference_mode():
+                ev_g, et_g = enc3(video=video3[:k], text={"input_ids": ids3[:k]})
+                v_cpu, ids_cpu = video3[:k].cpu(), ids3[:k].cpu()
+                O.encode_image(sd_t, v_cpu[0, :1])  # warm the thread pool
+                t0 = time.perf_counter()
+                ev_ref, et_ref = O.forward(sd_t, v_cpu, {"input_ids": ids_cpu})
+                cpu_s = time.perf_counter() - t0
+            result["cpu_baseline"] = {"value": round(k / cpu_s, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+                                      "sample": f"{k} clips x {args.frames} frames + {k} texts of the same data through the "
+                                                f"blended weights, fp32 PyTorch oracle, {cores} threads, {cpu_s:.1f} s"}
+            result["parity_vs_oracle_on_sample"] = {
+                "video_max_abs": float((ev_g.cpu() - ev_ref).abs().max()), "text_max_abs": float((et_g.cpu() - et_ref).abs().max()),
+                "tolerance": "fp32 path: embeddings <= 2e-5 (SURVEY 8(c))"}
         if rank == 0:
             print(json.dumps(result), flush=True)
         if grouped:

@@ -62,6 +62,7 @@ SIGNATURES = {
     "fc_pool_normalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "fc_l2_normalize": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "fc_similarity": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "fc_similarity_ranks": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "fc_ranks": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "fc_ranks_of": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "fc_group_mean": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "fc_kd_loss_rect": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "fc_wise": (_i32, [_vp, _vp, _f64, _vp, _sz, _vp]),
     "fc_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "fc_gemm_plan": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "fc_layernorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "fc_add_layernorm": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fc_attention": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

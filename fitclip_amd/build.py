@@ -19,6 +19,15 @@ HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "gemm_split3.h", CS
            REPO / "include" / "fitclip_hip.h"]
 ARCH = "gfx950"
 
+# Kernels the bench lines name (bench.py: `roofline.kernel`, the time split) must not touch scratch memory: a spilled register in
+# a kernel that lives at 256 VGPRs turns into scratch traffic inside the K loop.  Checked on the generated ISA after every
+# compile (source file -> substrings of the mangled kernel names); a violation fails the build.
+NO_SCRATCH_AUDIT = {
+    "gemm.hip": ["gemm_pipelined_kernel", "gemm_kernel"],
+    "attention.hip": ["attn_f32_blocks_kernel", "attn_f32_mfma_kernel", "attn_bf16_v2_kernel"],
+    "rowops.hip": ["layernorm_kernel", "layernorm_pair_kernel"],
+}
+
 
 def source_fingerprint() -> str:
     """Hash of every kernel / ABI source the library is built from.  Profiling artefacts (profiles/traffic_*.json) are
@@ -87,6 +96,37 @@ def audit_async_loads(asm_path: Path, kernel: str) -> int:
     return checked
 
 
+def kernel_resources(asm_path: Path):
+    """[{name, vgpr, agpr, sgpr, vgpr_spill, sgpr_spill, scratch, lds}] from the `amdhsa.kernels` metadata of a hipcc .s file."""
+    import re
+    text = asm_path.read_text()
+    md = text[text.index("amdhsa.kernels:"):]
+    out = []
+    for k in md.split("  - .agpr_count:")[1:]:
+        def num(key):
+            m = re.search(r"\.%s:\s+(\d+)" % key, k)
+            return int(m.group(1)) if m else -1
+        out.append({"name": re.search(r"\.name:\s+(\S+)", k).group(1), "agpr": int(k.split("\n")[0].strip()),
+                    "vgpr": num("vgpr_count"), "sgpr": num("sgpr_count"), "vgpr_spill": num("vgpr_spill_count"),
+                    "sgpr_spill": num("sgpr_spill_count"), "scratch": num("private_segment_fixed_size"),
+                    "lds": num("group_segment_fixed_size")})
+    return out
+
+
+def audit_no_scratch(asm_path: Path, substrings) -> int:
+    """Raises if a kernel whose name contains one of `substrings` spills a VGPR or owns scratch memory; returns the number checked."""
+    checked = 0
+    for k in kernel_resources(asm_path):
+        if any(sub in k["name"] for sub in substrings):
+            checked += 1
+            if k["vgpr_spill"] != 0 or k["scratch"] != 0:
+                raise RuntimeError(f"{asm_path.name}: {k['name']} spills {k['vgpr_spill']} VGPR(s), "
+                                   f"{k['scratch']} bytes of scratch per lane (.vgpr_spill_count / .private_segment_fixed_size must be 0)")
+    if checked == 0:
+        raise RuntimeError(f"{asm_path.name}: no kernel matches {substrings} (audit out of date?)")
+    return checked
+
+
 def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     objdir = CSRC / "build"
@@ -98,17 +138,22 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
         obj = objdir / (src.replace(".hip", ".o").replace(".cpp", ".o"))
         if force or _stale(obj, [CSRC / src, *HEADERS]):
             cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
-            if save_temps or src in ASYNC_LOAD_AUDIT:
+            if save_temps or src in ASYNC_LOAD_AUDIT or src in NO_SCRATCH_AUDIT:
                 cmd += ["-save-temps=obj"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True, cwd=str(objdir))
-            for kernel in ASYNC_LOAD_AUDIT.get(src, []):
-                try:
-                    audit_async_loads(objdir / (src.replace(".hip", "") + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s"), kernel)
-                except Exception:
-                    obj.unlink(missing_ok=True)  # never link an object that failed the audit
-                    raise
+            asm = objdir / (src.replace(".hip", "") + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+            try:
+                for kernel in ASYNC_LOAD_AUDIT.get(src, []):
+                    audit_async_loads(asm, kernel)
+                if src in NO_SCRATCH_AUDIT:
+                    n = audit_no_scratch(asm, NO_SCRATCH_AUDIT[src])
+                    if verbose:
+                        print(f"{src}: {n} kernel instantiation(s) audited: no VGPR spills, no scratch", flush=True)
+            except Exception:
+                obj.unlink(missing_ok=True)  # never link an object that failed an audit
+                raise
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:

@@ -5,7 +5,6 @@
 #include "handle.h"
 
 #include <cstdarg>
-#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <set>
@@ -39,6 +38,20 @@ hipError_t raise_dynamic_lds(const void* kernel, int bytes) {
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess) done.insert({dev, kernel});
   return e;
+}
+
+int device_cus() {
+  static std::mutex mu;
+  static std::map<int, int> known;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find(dev);
+  if (it != known.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  known[dev] = n;
+  return n;
 }
 
 }  // namespace fc
@@ -221,10 +234,12 @@ Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, b
 }
 
 // The 12 pre-LN residual blocks followed by the final LayerNorm of the pooled rows (CLS rows: pool_idx == nullptr,
-// row i * pool_step; EOT rows: pool_idx).  out_proj and c_proj add their result to the residual stream in their epilogue
-// (EPI_RESID_F32) and a plain LayerNorm follows.  The pooled rows of a pruned last block (and FITCLIP_NO_RESID_EPILOGUE=1,
-// the A/B switch): the projection writes its output ("delta", element type T) with a plain store epilogue and the residual
-// add x += delta is folded into the LayerNorm that follows it; in fp32 both forms perform the same fp32 add: same bits.
+// row i * pool_step; EOT rows: pool_idx).  out_proj and c_proj update the residual stream IN their epilogue
+// (EPI_RESID_F32: x += acc + bias), so the LayerNorm behind them reads one fp32 row and writes none back: fp32 8 instead of
+// 16 bytes per element in a pass that is HBM-bound, against 4 more bytes read by a GEMM that is MFMA-bound; the same fp32
+// add a fused add+LayerNorm performs - same bits (+1.3 % on the bench step).  bf16: 6 instead of 12 bytes in the LayerNorm
+// pass against 6 more in the GEMMs, which are closer to the memory there (+1.5 %); the stream receives the fp32 accumulator
+// instead of its bf16 rounding.
 //
 // cfg.prune_last_block: the towers only read the pooled row of each sequence after the last block, so in the last block
 // everything after the attention (out_proj, LayerNorm 2, c_fc, c_proj: 72 % of a block's FLOPs) is only computed for
@@ -243,13 +258,6 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
   const int esz = h->esz;
   const size_t nl = t.blocks.size();
   const long xs_pool = pool_idx ? w : pool_step * w;  // x row stride seen through the pooling index
-  // out_proj and c_proj update the residual stream IN their epilogue (EPI_RESID_F32: x += acc + bias), so the LayerNorm behind
-  // them reads one fp32 row and writes none back: fp32 8 instead of 16 bytes per element in a pass that is HBM-bound, against 4
-  // more bytes read by a GEMM that is MFMA-bound; the same fp32 add the fused add+LayerNorm did - same bits (+1.3 % on the bench
-  // step).  bf16: 6 instead of 12 bytes in the LayerNorm pass against 6 more in the GEMMs, which are closer to the memory there
-  // (+1.5 %); the stream receives the fp32 accumulator instead of its bf16 rounding.
-  static const bool no_fuse = getenv("FITCLIP_NO_RESID_EPILOGUE") != nullptr;  // A/B switch
-  const bool fuse = !no_fuse;
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
     if (l == 0 && entry) {
@@ -257,19 +265,16 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
                                    kind, M, w, st));
     } else if (l == 0) {
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
-    } else if (fuse) {
-      ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_add_layernorm(s.x, w, s.xn, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, 1, 0, st));
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
     }
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, 0, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
       FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
     }
-    if (l + 1 == nl && h->cfg.prune_last_block && fuse) {
+    if (l + 1 == nl && h->cfg.prune_last_block) {
       // the pooled rows of the attention output and of the residual stream, compact; then the block's tail as above
       const size_t blk = align_up((size_t)n_seq * w * 4);
       char* ao = s.big;                                   // [n, w] T   attention output
@@ -284,41 +289,15 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
       FC_TRY(gemm(h, EPI_RESID_F32, hc, b.proj_w, b.proj_b, xp, nullptr, n_seq, w, 4 * w, w, 0, st));
       return launch_layernorm(xp, w, nullptr, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);
     }
-    if (l + 1 == nl && h->cfg.prune_last_block) {
-      const size_t blk = align_up((size_t)n_seq * w * esz);
-      char* ao = s.big;           // [n, w]  pooled rows of the attention output
-      char* d1 = s.big + blk;     // [n, w]  out_proj delta
-      char* xc = s.big + 2 * blk; // [n, w]  LayerNorm 2 output
-      char* d2 = s.big + 3 * blk; // [n, w]  c_proj delta
-      char* hc = s.big + 4 * blk; // [n, 4w] MLP hidden
-      FC_TRY(launch_gather_rows(s.xn, pool_idx, pool_step, ao, n_seq, w * esz, st));
-      FC_TRY(gemm(h, EPI_BIAS_T, ao, b.out_w, b.out_b, d1, nullptr, n_seq, w, w, w, 0, st));
-      FC_TRY(launch_add_layernorm(s.x, xs_pool, d1, w, pool_idx, b.ln2_w, b.ln2_b, xc, w, kind, n_seq, w, 1, 1, st));
-      FC_TRY(gemm(h, EPI_GELU_T, xc, b.fc_w, b.fc_b, hc, nullptr, n_seq, 4 * w, w, 4 * w, 0, st));
-      FC_TRY(gemm(h, EPI_BIAS_T, hc, b.proj_w, b.proj_b, d2, nullptr, n_seq, w, 4 * w, w, 0, st));
-      return launch_add_layernorm(s.x, xs_pool, d2, w, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 1, st);
-    }
-    if (fuse) {
-      FC_TRY(gemm(h, EPI_RESID_F32, s.xn, b.out_w, b.out_b, s.x, nullptr, M, w, w, w, 0, st));
-      {
-        ProfScope ps(h, st, 2, M, w, 1);
-        FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, st));
-      }
-      FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
-      FC_TRY(gemm(h, EPI_RESID_F32, s.big, b.proj_w, b.proj_b, s.x, nullptr, M, w, 4 * w, w, 0, st));
-      continue;
-    }
-    FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.out_w, b.out_b, s.big, nullptr, M, w, w, w, 0, st));
+    FC_TRY(gemm(h, EPI_RESID_F32, s.xn, b.out_w, b.out_b, s.x, nullptr, M, w, w, w, 0, st));
     {
       ProfScope ps(h, st, 2, M, w, 1);
-      FC_TRY(launch_add_layernorm(s.x, w, s.big, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, 1, 0, st));
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, st));
     }
     FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, 0, st));
-    FC_TRY(gemm(h, EPI_BIAS_T, s.big, b.proj_w, b.proj_b, s.xn, nullptr, M, w, 4 * w, w, 0, st));
+    FC_TRY(gemm(h, EPI_RESID_F32, s.big, b.proj_w, b.proj_b, s.x, nullptr, M, w, 4 * w, w, 0, st));
   }
-  if (fuse) return launch_layernorm(s.x, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);
-  // the last c_proj delta is still pending in s.xn: fold it into the final LayerNorm of the pooled rows
-  return launch_add_layernorm(s.x, xs_pool, s.xn, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, 0, 0, st);
+  return launch_layernorm(s.x, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);
 }
 
 // ---- split-fp32 visual tower (cfg.split_gemm): the same block sequence with the four big GEMMs on the bf16 matrix
@@ -352,8 +331,6 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
   const size_t nl = t.blocks.size();
   // out_proj and c_proj update the residual stream in their epilogue (EPI_RESID3_F32, as the fp32 path's EPI_RESID_F32): the
   // LayerNorm behind them reads one fp32 row and writes the x3 rows - 12 instead of 20 bytes per element
-  static const bool no_fuse = getenv("FITCLIP_NO_RESID_EPILOGUE") != nullptr;  // A/B switch
-  const bool fuse = !no_fuse;
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
     if (l == 0) {
@@ -361,14 +338,12 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
                                    KIND_X3, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
-      if (fuse) FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, st));
-      else FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld3, KIND_X3, M, w, st));
     }
     FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.in_w3, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
-      static const bool f32_attention = getenv("FITCLIP_SPLIT_ATTN_F32") != nullptr;  // A/B switch: the fp32-MFMA kernel
-      if (attention_split_supported(S, 0) && !f32_attention) {
+      if (attention_split_supported(S, 0)) {
         FC_TRY(launch_attention_split(s.big, s.xn, n_seq, S, heads, st));
       } else if (attention_x3_supported(S, 0)) {
         FC_TRY(launch_attention_x3(s.big, s.xn, n_seq, S, heads, st));
@@ -377,82 +352,30 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
         FC_TRY(launch_split3_rows(s.d, w, s.xn, ld3, M, w, st));
       }
     }
-    if (fuse) FC_TRY(gemm_x3(h, EPI_RESID3_F32, s.xn, b.out_w3, b.out_b, s.x, M, w, w, w, st));
-    else FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.xn, b.out_w3, b.out_b, s.d, M, w, w, w, st));
+    FC_TRY(gemm_x3(h, EPI_RESID3_F32, s.xn, b.out_w3, b.out_b, s.x, M, w, w, w, st));
     {
       ProfScope ps(h, st, 2, M, w, 1);
-      if (fuse) FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, st));
-      else FC_TRY(launch_add_layernorm(s.x, w, s.d, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, 1, 0, st));
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld3, KIND_X3, M, w, st));
     }
     FC_TRY(gemm_x3(h, EPI_GELU_X3, s.xn, b.fc_w3, b.fc_b, s.big, M, 4 * w, w, (int)x3_row_elems(4 * w), st));
-    if (fuse) FC_TRY(gemm_x3(h, EPI_RESID3_F32, s.big, b.proj_w3, b.proj_b, s.x, M, w, 4 * w, w, st));
-    else FC_TRY(gemm_x3(h, EPI_BIAS_F32, s.big, b.proj_w3, b.proj_b, s.d, M, w, 4 * w, w, st));
+    FC_TRY(gemm_x3(h, EPI_RESID3_F32, s.big, b.proj_w3, b.proj_b, s.x, M, w, 4 * w, w, st));
   }
-  const long xs_pool = pool_step * w;
-  if (fuse) return launch_layernorm(s.x, xs_pool, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
-  // the last c_proj delta is still pending in s.d: fold it into the final LayerNorm of the pooled rows
-  return launch_add_layernorm(s.x, xs_pool, s.d, xs_pool, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, 0, 0, st);
+  return launch_layernorm(s.x, pool_step * w, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
 }
 
-int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return cus;
-}
-
-// Items per pass of a tower over `n` items.  bf16: up to 2048 frames (tile rounds do not matter there - when some CUs run
-// out of tiles the others speed up, the chip being power- and bandwidth-limited - but every pass pays its launches'
-// ramps: +2 % from 512 to 2048 frames).  fp32 is
-// MFMA-bound on every CU, so whole rounds of 256 x 256 tiles over the CUs matter: a pass whose number of 256-row panels is
-// a multiple of the CU count (ViT-B/16: 998 frames = 768 panels = 3, 9, 12 full rounds for the N = 768 / 2304 / 3072
-// GEMMs) runs its block GEMMs without a partial last round; 1024 frames would leave c_proj / out_proj at 9.23 rounds =
-// 92 %.  The pass size is chosen among those "whole round" sizes (and n itself) by the modelled number of tile rounds;
-// measured on the 2048-frame bench step: 433 pairs/s with 2 x 1024 frames, 450 with 998 + 998 + 52, 451 with 1663 + 385
-// (1280 panels: what the planner chose while a pass was bounded by 32-bit operand offsets, 1774 frames) - and, since the
-// GEMM addresses its activation rows from a 64-bit tile base, ONE pass of 2048 frames: the same modelled rounds (the
-// remainder of the last round runs as half tiles, gemm.hip), none of the second pass's launches - 464 -> 474 pairs/s.
+// Items per pass of a tower over `n` items: what bounds a pass is only the workspace it needs (3.6 MB per ViT-B/16 frame in
+// fp32; the GEMMs address their activation rows from 64-bit tile bases).  bf16 and fp32: up to 2048 frames - the measured
+// size (the bench step in ONE pass: bf16 3003 / 3023 / 3066 pairs/s with passes of 512 / 1024 / 2048 frames; fp32 464 -> 474
+// against 1663 + 385).  fp32 needs no "whole round" pass sizes any more (rounds 2-3 planned them): the GEMM launch cuts its
+// own rows into a head of whole tile rounds and a tail of lower tiles (gemm.hip: plan_tail).
+// Split-fp32 (bf16-pipe GEMMs): 768 frames - measured on the 2048-frame bench step (pairs/s): passes of 256 frames 594, 384:
+// 613, 512: 624, 600: 626, 700: 632, 768: 633-635, 850: 626, 886: 620, 665 (whole rounds): 607; 768: 704, 1024: 691, 2048: 697.
 int planned_chunk(const fc_handle* h, int tower, int n) {
+  (void)n;
   const fc_config& c = h->cfg;
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
-  if (c.precision != FC_PREC_F32) return 2048;  // (bench step, pairs/s: passes of 512 frames 3003, 1024: 3023, 2048: 3066)
-  const long T = h->vtokens(), w = c.vision_width, cus = device_cus();
-  if (h->split()) {
-    // bf16-pipe GEMMs: no whole-round planning, as in bf16 mode.  Measured on the 2048-frame bench step (pairs/s, share of the
-    // bf16 peak of the split GEMMs): passes of 256 frames 594 / 0.47, 384: 613 / 0.49, 512: 624 / 0.50, 600: 626, 700: 632,
-    // 768: 633-635 / 0.51, 850: 626, 886: 620; the planner's whole-round size (665 frames = 512 panels: 18 / 6 / 24 / 6 whole
-    // rounds) is the WORST of the large ones, 607 / 0.47 - with every workgroup of an XCD ending its tiles at the same moment
-    // the epilogue stores and the first DMA of the next tiles arrive in bursts.  Larger passes (possible since the kernel
-    // addresses its activation rows from 64-bit tile bases) do not help here: 768: 704, 1024: 691, 2048 (one pass): 697.
-    static const long split_pass = [] { const char* e = getenv("FITCLIP_SPLIT_PASS_FRAMES"); return e ? std::max(1L, atol(e)) : 768L; }();  // (A/B)
-    return (int)split_pass;
-  }
-  // (the pipelined GEMM addresses its activation rows from a 64-bit tile base; what bounds a pass is the workspace it needs -
-  // 3.6 MB per ViT-B/16 frame - so: at most 4096 frames, FITCLIP_MAX_PASS_FRAMES overrides for A/B runs)
-  static const long pass_cap = [] { const char* e = getenv("FITCLIP_MAX_PASS_FRAMES"); return e ? std::max(1L, atol(e)) : 4096L; }();
-  const long max_frames = pass_cap;
-  auto rounds = [&](long frames) {  // tile rounds x K-steps of the four block GEMMs of one pass
-    const long panels = (frames * T + 255) / 256;
-    const long shapes[4][2] = {{3 * w, w}, {w, w}, {4 * w, w}, {w, 4 * w}};
-    long total = 0;
-    for (auto& sh : shapes) total += (panels * ((sh[0] + 255) / 256) + cus - 1) / cus * (sh[1] / 32);
-    return total;
-  };
-  auto cost = [&](long chunk) { return (n / chunk) * rounds(chunk) + (n % chunk ? rounds(n % chunk) : 0); };
-  long best = std::min<long>(n, max_frames), best_cost = cost(best);
-  for (long j = 1; j <= 16; ++j) {
-    const long cand = j * cus * 256 / T;
-    if (cand > max_frames || cand >= n) break;
-    const long cc = cost(cand);
-    if (cc < best_cost || (cc == best_cost && cand > best)) best = cand, best_cost = cc;
-  }
-  return (int)best;
+  return h->split() ? 768 : 2048;
 }
 
 size_t per_item_bytes(const fc_handle* h, int tower) {
@@ -707,6 +630,10 @@ int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb, int32_
   a.M = na; a.N = nb; a.K = dim; a.lda = dim; a.ldw = dim; a.ldc = ldo; a.P = 0;
   return launch_gemm(PREC_F32, EPI_STORE_F32, a, 1, st);
 }
+int fc_similarity_ranks(const float* T, const float* V, int32_t nt, int32_t nv, int32_t dim, float alpha,
+                        int32_t target_offset, const int32_t* targets, int32_t* ranks, fc_stream st) {
+  return launch_similarity_ranks(T, V, nt, nv, dim, alpha, target_offset, targets, ranks, st);
+}
 int fc_ranks(const float* s, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t off, int32_t* ranks, fc_stream st) {
   return launch_ranks(s, ld, n_rows, n_cols, off, nullptr, ranks, st);
 }
@@ -737,6 +664,14 @@ int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const void* W, c
   a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = aux; a.alpha = alpha;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.P = P;
   return launch_gemm(precision, epilogue, a, tile, st);
+}
+int fc_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t* head_panels, int32_t* tail_units) {
+  if (M <= 0 || N <= 0 || K <= 0 || !head_panels || !tail_units) return fail(FC_EINVAL, "fc_gemm_plan: bad argument");
+  int hp = 0, ht = 0;
+  gemm_tail_plan(M, N, K, &hp, &ht);
+  *head_panels = hp;
+  *tail_units = ht;
+  return FC_OK;
 }
 int fc_layernorm(const float* x, int64_t xs, const int32_t* gather, const float* g, const float* b, void* y,
                  int64_t ys, int32_t out_kind, int32_t rows, int32_t D, fc_stream st) {

@@ -6,22 +6,17 @@
 // Sequences are short (197 visual tokens, 77 text tokens), so K and V of one (sequence, head) pair fit in LDS and the
 // softmax is single pass: no online rescaling, every score of a query row is in registers at once.
 //
-// bf16 kernel (throughput path), one workgroup = 4 waves per (sequence, head):
-//   * K tile in LDS as [key][64 d] rows of 128 B with the same 16-byte chunk swizzle as the GEMM (conflict-free
-//     ds_read_b128 of the MFMA A-operand); V is stored TRANSPOSED [d][key] (two keys packed per ds_write_b32) so the
-//     P.V B-operand (8 consecutive keys of one d) is two ds_read_b64.
+// bf16 kernels (throughput path): `attn_bf16_v2_kernel` (<= 224 tokens) and `attn_bf16_flash_kernel` (longer sequences), below.
+// Common to all MFMA kernels of this file:
 //   * S^T = K.Q^T is computed (keys on the accumulator rows, queries on the lanes, "swapped QK^T"): the softmax of a
 //     query is then a per-lane reduction over registers plus two cross-lane steps, and the exponentiated accumulator
-//     registers ARE the A-operand of P.V after a bf16 pack (cdna_hip_programming.md section 3, "An accumulator tile as
-//     the next MFMA's operand"): k-slot 8q+j of PV step ks maps to key 32ks + 16(j>>2) + 4q + (j&3), and the V^T
-//     fragment is gathered with the same map.
-//   * each wave owns 16-query tiles qt = wave, wave+4, ...; padded keys are masked to -inf, padded V rows are zero.
+//     registers ARE an operand of P.V (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand");
+//   * each wave owns 16-query tiles; padded keys are masked to -inf, padded V rows are zero.
 //
 // f32 kernel (parity path): plain VALU, one thread per query row, K/V broadcast from LDS, online softmax in fp32.
 #include "common.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace fc {
 
@@ -29,141 +24,10 @@ namespace {
 
 constexpr float kNegInf = -__builtin_inff();
 
-template <int NKT, bool CAUSAL>
-__global__ void __launch_bounds__(256) attn_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int S,
-                                                        int heads) {
-  constexpr int NK = NKT * 16;      // padded key count (multiple of 32)
-  constexpr int VS = (NK + 8) * 2;  // bytes per V^T row (pad keeps the ds_read_b64 pattern conflict-free)
-  static_assert(NKT % 2 == 0, "P.V consumes key tiles in pairs");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vt = smem + NK * 128;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
-  const int D = heads * 64;
-  const long ld = 3L * D;
-  const bf16* base = qkv + (long)seq * S * ld + h * 64;
-  const bf16* Qg = base;
-  const bf16* Kg = base + D;
-  const bf16* Vg = base + 2 * D;
-
-  const bf16x8 zero8 = {};
-  // ---- stage K (row-major, swizzled 16-byte chunks)
-  for (int idx = tid; idx < NK * 8; idx += 256) {
-    const int key = idx >> 3, c = idx & 7;
-    bf16x8 v = zero8;
-    if (key < S) v = *reinterpret_cast<const bf16x8*>(Kg + key * ld + c * 8);
-    *reinterpret_cast<bf16x8*>(Ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = v;
-  }
-  // ---- stage V transposed: item = (key pair p, d-chunk c)
-  for (int idx = tid; idx < (NK / 2) * 8; idx += 256) {
-    const int p = idx % (NK / 2), c = idx / (NK / 2);
-    const int k0 = 2 * p, k1 = 2 * p + 1;
-    bf16x8 v0 = zero8, v1 = zero8;
-    if (k0 < S) v0 = *reinterpret_cast<const bf16x8*>(Vg + k0 * ld + c * 8);
-    if (k1 < S) v1 = *reinterpret_cast<const bf16x8*>(Vg + k1 * ld + c * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      bf16x2 pr;
-      pr[0] = v0[j];
-      pr[1] = v1[j];
-      *reinterpret_cast<bf16x2*>(Vt + (c * 8 + j) * VS + k0 * 2) = pr;
-    }
-  }
-  __syncthreads();
-
-  const int r = lane & 15, q4 = lane >> 4, f = (r >> 1) & 7;
-  const int nqt = (S + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int query = qt * 16 + r;
-    const int qrow = min(query, S - 1);
-    bf16x8 qf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qg + qrow * ld + (4 * s + q4) * 8);
-
-    // S^T tiles: sT[t][reg] = score(key = 16t + 4*q4 + reg, query)
-    f32x4 sT[NKT];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (!CAUSAL || t <= qt) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + r) * 128 + (((4 * s + q4) ^ f) << 4));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc, 0, 0, 0);
-        }
-      }
-      sT[t] = acc;
-    }
-    // mask + softmax over keys (registers x tiles within the lane, then lanes l ^ 16, l ^ 32)
-    float mx = kNegInf;
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = t * 16 + 4 * q4 + e;
-        const bool ok = key < S && (!CAUSAL || key <= query);
-        const float v = ok ? sT[t][e] * 0.125f : kNegInf;
-        sT[t][e] = v;
-        mx = fmaxf(mx, v);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float p = __expf(sT[t][e] - mx);
-        sT[t][e] = p;
-        sum += p;
-      }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-
-    // O = P.V : A-operand = P (rows = queries on the lanes), B-operand = V^T fragment
-    f32x4 o[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < NKT / 2; ++ks) {
-      if (CAUSAL && 2 * ks > qt) continue;
-      bf16x8 pf;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pf[e] = static_cast<bf16>(sT[2 * ks][e]);
-        pf[4 + e] = static_cast<bf16>(sT[2 * ks + 1][e]);
-      }
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const char* vrow = Vt + (n * 16 + r) * VS + (ks * 32 + 4 * q4) * 2;
-        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
-        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 32);
-        const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
-      }
-    }
-    // o[n][e] = O(query' = 16 qt + 4 q4 + e, d = 16 n + r); the row sums live on lane (query' & 15)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float inv = 1.f / __shfl(sum, 4 * q4 + e, 64);
-      const int qo = qt * 16 + 4 * q4 + e;
-      if (qo < S) {
-        bf16* orow = out + ((long)seq * S + qo) * D + h * 64 + r;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) orow[n * 16] = static_cast<bf16>(o[n][e] * inv);
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// bf16 kernel, second generation (what the first profile asked for: the v1 kernel above spent its time in exposed
-// staging latency, 2-byte output stores and an unbalanced 13-tiles-over-4-waves split, not in MFMAs):
+// bf16 kernel (second generation; what the first profile asked for: the first kernel - V transposed through registers into
+// LDS, four waves - spent its time in exposed staging latency, 2-byte output stores and an unbalanced 13-tiles-over-4-waves
+// split, not in MFMAs):
 //   * K and V both arrive by LDS-DMA (`global_load_lds_dwordx4`, no VGPR round trip, issued once per workgroup and
 //     overlapped with the Q fragment loads); both stay ROW-major [key][64 d] in LDS.  K uses the 16-byte chunk swizzle
 //     of the GEMM (conflict-free ds_read_b128 of the QK^T A-operand); V uses a 32-byte granule swizzle
@@ -977,19 +841,6 @@ int launch_f32_blocks(const void* qkv, void* out, int n_seq, int S, int heads, h
   return FC_OK;
 }
 
-template <int NKT>
-int launch_bf16(const void* qkv, void* out, int n_seq, int S, int heads, int causal, hipStream_t st) {
-  constexpr int NK = NKT * 16;
-  constexpr int lds = NK * 128 + 64 * (NK + 8) * 2;
-  const dim3 grid(n_seq * heads), block(256);
-  if (causal)
-    hipLaunchKernelGGL((attn_bf16_kernel<NKT, true>), grid, block, lds, st, (const bf16*)qkv, (bf16*)out, S, heads);
-  else
-    hipLaunchKernelGGL((attn_bf16_kernel<NKT, false>), grid, block, lds, st, (const bf16*)qkv, (bf16*)out, S, heads);
-  FC_CHECK_LAUNCH("attention(bf16)");
-  return FC_OK;
-}
-
 }  // namespace
 
 // fp32 attention whose output is written as x3 rows [n_seq * S, 4 * heads * 64 bf16 positions] (split-fp32 mode).  Only the
@@ -1009,35 +860,21 @@ int launch_attention(int precision, const void* qkv, void* out, int n_seq, int S
   if (S <= 0 || heads <= 0) return fail(FC_EINVAL, "attention: S=%d heads=%d", S, heads);
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) return fail(FC_EINVAL, "attention: unaligned operand");
   if (precision == PREC_BF16) {
-    static const bool use_v1 = getenv("FITCLIP_ATTN_V1") != nullptr;  // A/B switch for the first-generation kernel
-    if (!use_v1) {
-      if (S <= 32) return launch_bf16_v2<2, 2>(qkv, out, n_seq, S, heads, causal, stream);
-      if (S <= 96) return launch_bf16_v2<6, 5>(qkv, out, n_seq, S, heads, causal, stream);
-      if (S <= 224) {
-        // 8 waves: every workgroup puts two waves on each SIMD (7 waves for the 13 query tiles of the ViT left one SIMD
-        // with a single wave per workgroup); FITCLIP_ATTN_7WAVES=1 is the A/B switch
-        static const bool seven = getenv("FITCLIP_ATTN_7WAVES") != nullptr;
-        return seven ? launch_bf16_v2<14, 7>(qkv, out, n_seq, S, heads, causal, stream)
-                     : launch_bf16_v2<14, 8>(qkv, out, n_seq, S, heads, causal, stream);
-      }
-      if (causal) return fail(FC_EINVAL, "attention(bf16): causal attention over %d > 224 tokens is not supported", S);
-      return launch_bf16_flash(qkv, out, n_seq, S, heads, stream);
-    }
-    if (S <= 32) return launch_bf16<2>(qkv, out, n_seq, S, heads, causal, stream);
-    if (S <= 96) return launch_bf16<6>(qkv, out, n_seq, S, heads, causal, stream);
-    if (S <= 224) return launch_bf16<14>(qkv, out, n_seq, S, heads, causal, stream);
-    return fail(FC_EINVAL, "attention(bf16): sequence length %d > 224 not supported", S);
+    if (S <= 32) return launch_bf16_v2<2, 2>(qkv, out, n_seq, S, heads, causal, stream);
+    if (S <= 96) return launch_bf16_v2<6, 5>(qkv, out, n_seq, S, heads, causal, stream);
+    // 8 waves: every workgroup puts two waves on each SIMD (7 waves for the 13 query tiles of the ViT left one SIMD with a
+    // single wave per workgroup)
+    if (S <= 224) return launch_bf16_v2<14, 8>(qkv, out, n_seq, S, heads, causal, stream);
+    if (causal) return fail(FC_EINVAL, "attention(bf16): causal attention over %d > 224 tokens is not supported", S);
+    return launch_bf16_flash(qkv, out, n_seq, S, heads, stream);
   }
-  static const bool f32_valu = getenv("FITCLIP_ATTN_F32_VALU") != nullptr;  // A/B switch for the thread-per-query kernel
-  if (!f32_valu && S <= 288) {  // K and V of one (sequence, head) fit LDS in fp32 up to 288 tokens (144 KiB)
+  if (S <= 288) {  // K and V of one (sequence, head) fit LDS in fp32 up to 288 tokens (144 KiB)
     if (S <= 96)
       return causal ? launch_f32_mfma<6, 6, true>(qkv, out, n_seq, S, heads, stream)
                     : launch_f32_mfma<6, 6, false>(qkv, out, n_seq, S, heads, stream);
     if (S <= 224) {
-      static const bool one_block = getenv("FITCLIP_ATTN_F32_ONE_BLOCK") != nullptr;  // A/B switch: first generation
-      if (!causal && !one_block) return launch_f32_blocks(qkv, out, n_seq, S, heads, stream);
-      return causal ? launch_f32_mfma<14, 14, true>(qkv, out, n_seq, S, heads, stream)
-                    : launch_f32_mfma<14, 14, false>(qkv, out, n_seq, S, heads, stream);
+      if (!causal) return launch_f32_blocks(qkv, out, n_seq, S, heads, stream);
+      return launch_f32_mfma<14, 14, true>(qkv, out, n_seq, S, heads, stream);
     }
     return causal ? launch_f32_mfma<18, 8, true>(qkv, out, n_seq, S, heads, stream)
                   : launch_f32_mfma<18, 8, false>(qkv, out, n_seq, S, heads, stream);

@@ -16,7 +16,6 @@
 // Operand layouts, swizzles and the "accumulator as the next MFMA's operand" trick are those of attn_f32_mfma_kernel.
 #include "common.h"
 
-#include <cstdlib>
 
 namespace fc {
 
@@ -283,10 +282,7 @@ int launch_attention_backward(int precision, const void* qkv, const void* o, con
     return causal ? launch_bwd_variant<6, 6, true>(q, oo, dd, dq, n_seq, S, heads, stream)
                   : launch_bwd_variant<6, 6, false>(q, oo, dd, dq, n_seq, S, heads, stream);
   if (S <= 224) {
-    static const bool seven = getenv("FITCLIP_ATTN_7WAVES") != nullptr;  // A/B switch: 7 waves left one SIMD with one wave
-    if (seven)
-      return causal ? launch_bwd_variant<14, 7, true>(q, oo, dd, dq, n_seq, S, heads, stream)
-                    : launch_bwd_variant<14, 7, false>(q, oo, dd, dq, n_seq, S, heads, stream);
+    // (8 waves: 7 left one SIMD with a single wave)
     return causal ? launch_bwd_variant<14, 8, true>(q, oo, dd, dq, n_seq, S, heads, stream)
                   : launch_bwd_variant<14, 8, false>(q, oo, dd, dq, n_seq, S, heads, stream);
   }

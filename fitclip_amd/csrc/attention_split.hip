@@ -538,13 +538,10 @@ int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int hea
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 127)) return fail(FC_EINVAL, "attention(split): unaligned operand");
   const long items = (long)n_seq * heads;
   if (items > 0x7fffffffL) return fail(FC_EINVAL, "attention(split): %ld (sequence, head) pairs", items);
-  static const hipError_t raised = raise_dynamic_lds((const void*)attn_split_kernel<0>, ATTN_SPLIT_LDS);  // the six planes: one workgroup per CU
-  if (raised != hipSuccess) return fail(FC_ELAUNCH, "attention(split): cannot raise dynamic LDS");
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
+  // (per launch: raise_dynamic_lds memoises per (device, kernel), and the CU count belongs to the current device as well)
+  if (raise_dynamic_lds((const void*)attn_split_kernel<0>, ATTN_SPLIT_LDS) != hipSuccess)  // the six planes: one workgroup per CU
+    return fail(FC_ELAUNCH, "attention(split): cannot raise dynamic LDS");
+  const int cus = device_cus();
   hipLaunchKernelGGL((attn_split_kernel<0>), dim3((unsigned)std::min<long>(items, cus)), dim3(NT), ATTN_SPLIT_LDS, stream,
                      (const float*)qkv, (char*)out, S, heads, (int)items, (long long*)nullptr);
   FC_CHECK_LAUNCH("attention(split)");

@@ -26,6 +26,8 @@ int fail(int code, const char* fmt, ...);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): the attribute belongs to the function on the
 // CURRENT device, and a process may hold handles on several devices.  Thread-safe.  Returns hipSuccess or the error.
 hipError_t raise_dynamic_lds(const void* kernel, int bytes);
+// compute units of the CURRENT device (memoised per device; 256 if the query fails): grid size of the persistent kernels
+int device_cus();
 
 #define FC_CHECK_LAUNCH(what)                                                          \
   do {                                                                                 \
@@ -45,6 +47,7 @@ enum Epilogue : int {
   EPI_BIAS_F32 = 6,   // gemm_split3 only: C(f32) = acc + bias                  (three-plane operands in, fp32 out)
   EPI_GELU_X3 = 7,    // gemm_split3 only: C(x3 rows [M, 4 N bf16]) = three_planes(quickgelu(acc + bias))   (the next GEMM's A operand)
   EPI_RESID3_F32 = 8, // gemm_split3 only: C(f32) += acc + bias           (three-plane operands in; the residual stream updated in place)
+  EPI_RANKS_I32 = 9,  // f32 only (launch_similarity_ranks): C(int32[M]) += #{n : s[m,n] > s[m,t_m] or (== and n < t_m)}, s = alpha acc
 };
 
 // ---- split-fp32 operands.  An fp32 number is exactly the sum of three bf16 numbers, x = p1 + p2 + p3 (p1 = bf16(x),
@@ -89,9 +92,14 @@ struct GemmArgs {
   // EPI_PATCH_F32 with T = float: gR > 0 makes A the FRAMES f32 [n, 3, gR, gR]; row m = (image, patch) and column
   // k = (channel, py, px) of the im2col matrix are gathered by the LDS-DMA loader itself (no im2col pass in HBM).
   int gR, gP;
+  int hp;             // pipelined kernel with a tail of lower tiles (gemm_kernel.h, HT > 0): 256-row panels of the head
+  // EPI_RANKS_I32: target column of row m = targets ? targets[m] : m + tgt_off (clamped to [0, N)); every workgroup walks `ctw`
+  // column tiles of its row block (grid = row blocks x ceil(column tiles / ctw))
+  const int32_t* targets;
+  int tgt_off, ctw;
 };
 
-// tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)
+// tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = persistent pipelined, 4..7 = pipelined with a forced row cut (gemm.hip)
 int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStream_t stream);
 // split-fp32 GEMM over three-plane operands (gemm_split3.h).  a.K counts fp32 columns; a.lda / a.ldw count bf16 positions of
 // the x3 rows (>= 4 K); a.ldc counts floats (EPI_BIAS_F32) or bf16 positions of the x3 output rows (EPI_GELU_X3, >= 4 N)
@@ -99,6 +107,9 @@ int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream);
 bool gemm_split3_ok(const GemmArgs& a);
 // x3 image [rows, 4 K bf16] of fp32 rows [rows, K]
 int launch_split3_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, hipStream_t stream);
+// the row cut of the fp32 pipelined kernel for an [M, N] output over K columns on the current device: 256-row panels of the head (whole tile
+// rounds) and the height of the tail tiles in 64-row units (0 = no tail)
+void gemm_tail_plan(int M, int N, int K, int* head_panels, int* tail_units);
 // which kernel `tile` = 0 resolves to: 1 / 2 = one-tile-per-workgroup 128x128 / 256x256, 3 = persistent pipelined
 int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile);
 
@@ -146,6 +157,11 @@ int launch_transpose_convert(const float* in, void* out, int out_kind, int rows,
 int launch_wise(const float* a, const float* b, double w, float* out, size_t n, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- score
+// ranks[i] = rank of column t_i in the stable descending order of row i of alpha * T @ V^T, WITHOUT the [nt, nv] matrix in
+// memory: the comparison runs in the epilogue of the scoring GEMM (gemm_kernel.h, EPI_RANKS_I32); same bits as
+// launch_gemm(EPI_STORE_F32) + launch_ranks
+int launch_similarity_ranks(const float* T, const float* V, int nt, int nv, int dim, float alpha, int target_offset,
+                            const int32_t* targets, int32_t* ranks, hipStream_t stream);
 // rank of column targets[i] (or i + target_offset when targets == nullptr) in the stable descending order of row i
 int launch_ranks(const float* scores, int ld, int n_rows, int n_cols, int target_offset, const int32_t* targets,
                  int32_t* ranks, hipStream_t stream);

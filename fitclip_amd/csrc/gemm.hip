@@ -1,6 +1,4 @@
 // Host-side dispatch of the MFMA GEMM (kernel: gemm_kernel.h).
-#include <cstdlib>
-
 #include "gemm_kernel.h"
 
 #include <algorithm>
@@ -21,30 +19,56 @@ int launch_one(const GemmArgs& a, hipStream_t stream) {
   return FC_OK;
 }
 
-int num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return cus;
-}
-
-// persistent, pipelined kernel: one workgroup per CU walks the tiles (BM = 256; 128 for the tail launch below)
-template <typename T, int EPI, int SCHED, int BM = 256>
-int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
-  constexpr int BN = 256, WM = 2, WN = 4;
+// persistent, pipelined kernel: one workgroup per CU walks its tiles (HT > 0: head panels g.hp, then a tail of HT x 64-row tiles)
+template <typename T, int EPI, int SCHED, int HT>
+int launch_pipelined_ht(const GemmArgs& a, hipStream_t stream) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
   constexpr int lds = 2 * (BM + BN) * ROWB + WM * WN * 2048 + 2048;  // two stages + a 2 KiB output patch per wave + bias
-  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, 0, 1, SCHED>;
+  auto kern = gemm_pipelined_kernel<T, BM, BN, WM, WN, EPI, 0, 1, SCHED, HT>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);
-  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, num_cus())), dim3(WM * WN * 64), lds, stream, a);
+  const long tilesN = (a.N + BN - 1) / BN;
+  long work = (long)((a.M + BM - 1) / BM) * tilesN;
+  if constexpr (HT > 0) {
+    const long rows = a.M - (long)a.hp * BM;
+    work = std::max((long)a.hp * tilesN, (rows + 64 * HT - 1) / (64 * HT) * tilesN);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(work, device_cus())), dim3(WM * WN * 64), lds, stream, a);
   FC_CHECK_LAUNCH("gemm(pipelined)");
   return FC_OK;
+}
+
+// fp32 is MFMA-bound on every CU, so a partial last round of 256 x 256 tiles costs a whole round (a small batch - the
+// reference evaluates 32 clips = 128 frames at a time - cannot be planned around that: out_proj / c_proj have 297 tiles for
+// 256 CUs).  The rows are cut in a head of `hp` panels, whose tiles fill whole rounds, and a tail walked as tiles of
+// ht x 64 rows by the same launch (gemm_kernel.h); (hp, ht) minimise the modelled time: rounds of head tiles + rounds of tail
+// tiles x the relative cost of a tile of that height (proportional to the height, plus what a lower tile hides less well: its
+// weight tile is staged for fewer rows, its prologue and epilogue are paid per tile).  Same K order per output element: results
+// are bit-identical whatever the cut.  bf16 keeps whole 256-row tiles: there the chip is power- and bandwidth-limited and a
+// partial round costs nothing measurable.
+struct TailPlan { int hp, ht; };
+// Relative cost of a tail tile of ht x 64 rows against a 256-row tile, fitted to forced cuts of the block shapes at 128 frames
+// (tools/bench_gemm.py --tiles 4,5,6,7; M = 25 216): a tile takes ~1.7 us per K-step and 64-row unit, plus ~0.26 us per K-step
+// and ~28 us per tile that do not shrink with its height (hand-over, weight staging, the exposed ends of the tail phase):
+//   K = 768 (24 K-steps): 0.46 / 0.71 / 0.96 of a full tile for 1 / 2 / 3 units;  K = 3072: 0.33 / 0.58 / 0.83.
+double tail_tile_cost(int ht, int nk) { return ht / 4.0 + 0.04 + 4.0 / std::max(nk, 1); }
+TailPlan plan_tail(int M, int tilesN, int nk, int cus) {
+  const int panels = (M + 255) / 256;
+  const long full_rounds = (long)panels * tilesN / cus;
+  TailPlan best{panels, 0};
+  double best_cost = (double)(((long)panels * tilesN + cus - 1) / cus);
+  for (long r = full_rounds; r >= std::max(0L, full_rounds - 1); --r) {
+    const int hp = (int)std::min<long>(panels, r * cus / tilesN);
+    const long rows = (long)M - (long)hp * 256;
+    if (rows <= 0) continue;
+    const double head = (double)(((long)hp * tilesN + cus - 1) / cus);
+    for (int ht = 1; ht <= 3; ++ht) {
+      const long tiles = (rows + 64 * ht - 1) / (64 * ht) * tilesN;
+      const double c = head + (double)((tiles + cus - 1) / cus) * tail_tile_cost(ht, nk);
+      if (c < best_cost - 1e-9) best_cost = c, best = TailPlan{hp, ht};
+    }
+  }
+  return best;
 }
 
 // LDS-DMA issue schedule (gemm_kernel.h: piece_slot).  Lab (tools/gemm_lab, profiles/r01_lab17_sched.log): the K = 768
@@ -52,60 +76,28 @@ int launch_pipelined_sched(const GemmArgs& a, hipStream_t stream) {
 // c_proj, which streams its activations from HBM, 4 % from requesting them early (2: activations in the hand-over,
 // weights after group 0).  In situ (kernel traces of bench.py per schedule, tools/sched_ab.sh,
 // profiles/r01_sched_in_situ.txt) only c_fc keeps the gain of 8 (433 vs 448 / 462 us for 2 / 0); QKV is indifferent
-// between 2 and 8, out_proj and c_proj are fastest with 2.  Hence: 8 for the QuickGELU GEMM, 2 otherwise.
-// FITCLIP_GEMM_SCHED=0|2|8 overrides (A/B runs); the result does not depend on the schedule.
+// between 2 and 8, out_proj and c_proj are fastest with 2.  Hence: 8 for the QuickGELU GEMM, 2 otherwise.  The result does
+// not depend on the schedule.
+// forced_ht: -1 = the planned cut; 0 = whole 256-row tiles only; 1..3 = a tail of that height behind the largest head of whole
+// rounds (tests: every instantiation against the plain kernels)
 template <typename T, int EPI>
-int launch_pipelined_full(const GemmArgs& a, hipStream_t stream) {
-  static const int forced = [] {
-    const char* e = getenv("FITCLIP_GEMM_SCHED");
-    return e ? atoi(e) : -1;
-  }();
-  const int sched = forced >= 0 ? forced : (EPI == EPI_GELU_T ? 8 : 2);
-  switch (sched) {
-    case 2: return launch_pipelined_sched<T, EPI, 2>(a, stream);
-    case 8: return launch_pipelined_sched<T, EPI, 8>(a, stream);
-    default: return launch_pipelined_sched<T, EPI, 0>(a, stream);
-  }
-}
-
-// fp32 is MFMA-bound on every CU, so a partial last round of 256 x 256 tiles costs a whole round (api.hip plans the
-// passes of a big batch around that; a small batch - the reference evaluates 32 clips = 128 frames at a time - cannot be
-// planned).  Here the row panels that fill whole rounds go to one launch and the REST to a second launch of 128 x 256
-// tiles when its half-size rounds are cheaper (c_proj / out_proj of 128 frames: 297 tiles = 2 rounds -> 591 half tiles =
-// 3 half rounds; QKV of 385 frames: 11 -> 9 + 1.6 rounds).  Same K order per output element: results are bit-identical.
-template <typename T, int EPI>
-int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
+int launch_pipelined(const GemmArgs& a, int forced_ht, hipStream_t stream) {
+  constexpr int SCHED = EPI == EPI_GELU_T ? 8 : 2;
   if constexpr (sizeof(T) == 4) {
-    static const bool no_tail = getenv("FITCLIP_GEMM_NO_TAIL") != nullptr;  // A/B switch
-    const int cus = num_cus(), tilesN = (a.N + 255) / 256, panels = (a.M + 255) / 256;
-    int g = cus, t = tilesN;
-    while (t) { const int r = g % t; g = t; t = r; }  // gcd
-    const int step = cus / g;                          // panels per whole number of rounds
-    const int p0 = panels / step * step;
-    const long rem_tiles = (long)(panels - p0) * tilesN;
-    if (rem_tiles > 0 && !no_tail) {
-      const int rem_rows = a.M - p0 * 256;
-      const long half_tiles = (long)((rem_rows + 127) / 128) * tilesN;
-      const double cost256 = (double)((rem_tiles + cus - 1) / cus);
-      const double cost128 = 0.54 * (double)((half_tiles + cus - 1) / cus);  // a 128-row tile: half the work at ~92 % of the rate
-      if (cost128 < cost256) {
-        if (p0 > 0) {
-          GemmArgs head = a;
-          head.M = p0 * 256;
-          const int rc = launch_pipelined_full<T, EPI>(head, stream);
-          if (rc != FC_OK) return rc;
-        }
-        GemmArgs tail = a;
-        const size_t r0 = (size_t)p0 * 256;
-        tail.M = rem_rows;
-        tail.A = static_cast<const char*>(a.A) + r0 * a.lda * sizeof(T);
-        tail.C = static_cast<char*>(a.C) + r0 * a.ldc * sizeof(T);
-        if constexpr (EPI == EPI_DGELU_T) tail.aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.aux) + r0 * a.ldc * sizeof(T));
-        return launch_pipelined_sched<T, EPI, 0, 128>(tail, stream);
-      }
+    const int panels = (a.M + 255) / 256, tilesN = (a.N + 255) / 256, cus = device_cus();
+    TailPlan p = plan_tail(a.M, tilesN, a.K / (ROWB / 4), cus);
+    if (forced_ht == 0) p = TailPlan{panels, 0};
+    if (forced_ht > 0) p = TailPlan{(int)std::min<long>(panels - 1, (long)panels * tilesN / cus * cus / tilesN), forced_ht};
+    GemmArgs b = a;
+    b.hp = p.hp;
+    switch (p.ht) {
+      case 1: return launch_pipelined_ht<T, EPI, SCHED, 1>(b, stream);
+      case 2: return launch_pipelined_ht<T, EPI, SCHED, 2>(b, stream);
+      case 3: return launch_pipelined_ht<T, EPI, SCHED, 3>(b, stream);
+      default: return launch_pipelined_ht<T, EPI, SCHED, 0>(b, stream);
     }
   }
-  return launch_pipelined_full<T, EPI>(a, stream);
+  return launch_pipelined_ht<T, EPI, SCHED, 0>(a, stream);
 }
 
 template <typename T>
@@ -125,15 +117,18 @@ int resolve_tile(int epi, const GemmArgs& a, int tile) {
   return t256 >= 512 ? 2 : 1;
 }
 
-// tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (BIAS_T / GELU_T only)
+// tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (the block epilogues); 4..7 = the
+// pipelined kernel with its fp32 row cut forced: 4 = whole tiles only, 5..7 = a tail of 1..3 x 64-row tiles
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
+  const int forced_ht = tile >= 4 ? tile - 4 : -1;
+  if (tile >= 4) tile = 3;
   constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
     if constexpr (kHasPipelined) {
       if (!pipelined_ok<T>(a)) return fail(FC_EINVAL, "gemm: shape not supported by the pipelined kernel");
-      return launch_pipelined<T, EPI>(a, stream);
+      return launch_pipelined<T, EPI>(a, forced_ht, stream);
     } else {
       return fail(FC_EINVAL, "gemm: the pipelined kernel has no epilogue %d", EPI);
     }
@@ -151,6 +146,7 @@ int launch_epi(int epi, const GemmArgs& a, int tile, hipStream_t stream) {
     case EPI_PATCH_F32: return launch_tile<T, EPI_PATCH_F32>(a, tile, stream);
     case EPI_STORE_F32: return launch_tile<T, EPI_STORE_F32>(a, tile, stream);
     case EPI_DGELU_T: return launch_tile<T, EPI_DGELU_T>(a, tile, stream);
+    case EPI_RANKS_I32: return fail(FC_EINVAL, "gemm: the ranks epilogue belongs to fc_similarity_ranks");
     case EPI_BIAS_F32:
     case EPI_GELU_X3:
     case EPI_RESID3_F32: return fail(FC_EINVAL, "gemm: epilogue %d belongs to the three-plane split-fp32 GEMM (fc_gemm_split3)", epi);
@@ -160,7 +156,41 @@ int launch_epi(int epi, const GemmArgs& a, int tile, hipStream_t stream) {
 
 }  // namespace
 
+void gemm_tail_plan(int M, int N, int K, int* head_panels, int* tail_units) {
+  const TailPlan p = plan_tail(M, (N + 255) / 256, K / (ROWB / 4), device_cus());
+  *head_panels = p.hp;
+  *tail_units = p.ht;
+}
+
+// Ranks of the target columns of alpha * T @ V^T without the matrix (gemm_kernel.h, EPI_RANKS_I32): row blocks of 128 texts x
+// groups of `ctw` column tiles, enough workgroups for two per CU; the integer counts of a row's column groups meet in `ranks`
+// by atomicAdd (integers: the order does not matter), which is zeroed first on the same stream.
+int launch_similarity_ranks(const float* T, const float* V, int nt, int nv, int dim, float alpha, int target_offset,
+                            const int32_t* targets, int32_t* ranks, hipStream_t stream) {
+  if (nt == 0) return FC_OK;
+  if (nt < 0 || nv <= 0 || dim <= 0 || !T || !V || !ranks) return fail(FC_EINVAL, "similarity_ranks: bad argument");
+  if (dim % 32) return fail(FC_EINVAL, "similarity_ranks: dim=%d must be a multiple of 32", dim);
+  if (((uintptr_t)T | (uintptr_t)V) & 15) return fail(FC_EINVAL, "similarity_ranks: unaligned operand");
+  constexpr int B = 128;
+  constexpr int lds = 2 * (B + B) * ROWB;
+  auto kern = gemm_kernel<float, B, B, 2, 2, EPI_RANKS_I32>;
+  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "similarity_ranks: cannot raise dynamic LDS to %d bytes", lds);
+  if (hipMemsetAsync(ranks, 0, (size_t)nt * sizeof(int32_t), stream) != hipSuccess)
+    return fail(FC_ELAUNCH, "similarity_ranks: hipMemsetAsync failed");
+  GemmArgs a{};
+  a.A = T; a.W = V; a.C = ranks; a.alpha = alpha; a.M = nt; a.N = nv; a.K = dim; a.lda = dim; a.ldw = dim; a.ldc = 1;
+  a.targets = targets; a.tgt_off = target_offset;
+  const int tilesM = (nt + B - 1) / B, tilesN = (nv + B - 1) / B;
+  const int splits = std::max(1, std::min(tilesN, (2 * device_cus() + tilesM - 1) / tilesM));
+  a.ctw = (tilesN + splits - 1) / splits;
+  hipLaunchKernelGGL(kern, dim3(tilesM * ((tilesN + a.ctw - 1) / a.ctw)), dim3(256), lds, stream, a);
+  FC_CHECK_LAUNCH("similarity_ranks");
+  return FC_OK;
+}
+
 int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile) {
+  if (tile >= 4) tile = 3;
   return precision == PREC_BF16 ? resolve_tile<bf16>(epilogue, a, tile) : resolve_tile<float>(epilogue, a, tile);
 }
 
@@ -184,7 +214,7 @@ int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStr
         G * G != a.P || a.K != 3 * a.gP * a.gP)
       return fail(FC_EINVAL, "gemm: patch gather needs the f32 patch-embed epilogue, patch %% 4 == 0 and K = 3 p^2");
   }
-  if (tile < 0 || tile > 3) return fail(FC_EINVAL, "gemm: tile=%d", tile);
+  if (tile < 0 || tile > 7) return fail(FC_EINVAL, "gemm: tile=%d", tile);
   return precision == PREC_BF16 ? launch_epi<bf16>(epilogue, a, tile, stream)
                                 : launch_epi<float>(epilogue, a, tile, stream);
 }

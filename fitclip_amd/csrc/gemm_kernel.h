@@ -105,9 +105,17 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   constexpr int LPW = RG / NW;       // glds per wave per stage
   static_assert(RG % NW == 0, "row groups must divide over the waves");
   static_assert(BM % 16 == 0 && BN % 16 == 0, "tile");
+  // EPI_RANKS_I32 (scoring without the score matrix): the workgroup owns the row block blockIdx % tilesM and walks g.ctw column
+  // tiles of it.  FIRST it multiplies its rows with the rows' own TARGET columns (the weight tile gathers row t_m of W for
+  // local row m) and keeps the diagonal - s[m, t_m], by the same MFMA chain in the same K order as any other element of the
+  // product, i.e. with the bits fc_similarity would have stored - in LDS; then, tile by tile, every lane compares its
+  // alpha * acc with its row's reference and counts.  No [M, N] store.
+  constexpr bool kRanks = EPI == EPI_RANKS_I32;
+  static_assert(!kRanks || (sizeof(T) == 4 && BM == BN && WM == WN), "ranks epilogue: square fp32 tile, diagonal inside the diagonal waves");
   using FragT = typename Frag<T>::type;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float diag_s[kRanks ? BM : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,8 +126,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int xcd = orig & 7, qd = nwg >> 3, rd = nwg & 7;
   const int t = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
-  const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
+  const int tilesM = (g.M + BM - 1) / BM;
+  const int m0 = kRanks ? (t % tilesM) * BM : (t / tilesN) * BM;
+  const int ct0 = kRanks ? (t / tilesM) * g.ctw : t % tilesN;               // first column tile
+  const int npass = kRanks ? min(g.ctw, tilesN - ct0) : 1;                  // column tiles of this workgroup
+  const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
+  int cnt[kRanks ? FM : 1] = {};
 
+  for (int pass = kRanks ? -1 : 0; pass < npass; ++pass) {   // (ranks: pass -1 = the rows' own target columns)
+  const int n0 = (ct0 + max(pass, 0)) * BN;
   // ---- per-lane staging sources
   const char* src[LPW];
   // patch gather (EPI_PATCH_F32, f32, g.gR > 0): the A row of an (image, patch) pair is not contiguous - its 16-byte
@@ -147,7 +162,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
         }
         src[i] = reinterpret_cast<const char*>(g.A) + ((size_t)gr * g.lda) * sizeof(T) + chunk * 16;
       } else {
-        const int gr = min((ABL == 2 ? 0 : n0) + row - BM, g.N - 1);
+        int gr = min((ABL == 2 ? 0 : n0) + row - BM, g.N - 1);
+        if constexpr (kRanks) {
+          if (pass < 0) {  // the target column of local row (row - BM)
+            const int m = min(m0 + row - BM, g.M - 1);
+            gr = min(max(g.targets ? g.targets[m] : m + g.tgt_off, 0), g.N - 1);
+          }
+        }
         src[i] = reinterpret_cast<const char*>(g.W) + ((size_t)gr * g.ldw) * sizeof(T) + chunk * 16;
       }
     }
@@ -170,7 +191,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
     }
   };
 
-  const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
   // The two store epilogues and the residual update start the accumulators from the bias (as the pipelined kernel does, so
   // both kernels produce bit-identical results and a row's value does not depend on which one the batch size selects).
   constexpr bool kBiasInit = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32;
@@ -188,9 +208,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
 
   const int nk = g.K / BKE;
   // the two block-GEMM epilogues use the rotated K order of gemm_pipelined_kernel (bit-identical results); scoring
-  // (EPI_STORE_F32) and patch embedding keep the natural order, so a score does not depend on its column position
+  // (EPI_STORE_F32 / EPI_RANKS_I32) and patch embedding keep the natural order, so a score does not depend on its column position
   const int rot = kBiasInit ? (n0 >> 8) % nk : 0;
   auto krot = [&](int kt) { return kt + rot >= nk ? kt + rot - nk : kt + rot; };
+  if constexpr (kRanks) __syncthreads();  // (every wave has left the previous pass's last stage)
   stage_load(0, krot(0));
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,6 +241,37 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
           for (int j = 0; j < FN; ++j) mma<T>(wb[j], xa[i], acc[i][j]);
       }
     }
+  }
+
+  if constexpr (kRanks) {
+    if (pass < 0) {
+      // local row m = wm TM + 16 i + r meets its own column in wave wn == wm, fragment j == i, lane group q == r / 4, element r % 4
+      if (wm == wn && q == (r >> 2)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const f32x4 v = acc[i][i] * g.alpha;
+          diag_s[wm * TM + i * 16 + r] = (r & 3) == 0 ? v[0] : (r & 3) == 1 ? v[1] : (r & 3) == 2 ? v[2] : v[3];
+        }
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int ml = wm * TM + i * 16 + r, m = min(m0 + ml, g.M - 1);
+        const float ref = diag_s[ml];
+        const int tcol = min(max(g.targets ? g.targets[m] : m + g.tgt_off, 0), g.N - 1);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const f32x4 v = acc[i][j] * g.alpha;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn * TN + j * 16 + 4 * q + e;
+            cnt[i] += (n < g.N) && ((v[e] > ref) || (v[e] == ref && n < tcol));
+          }
+        }
+      }
+    }
+    continue;
   }
 
   if constexpr (ABL == 3) {
@@ -264,13 +316,25 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(pre[e]);
         store4<T>(reinterpret_cast<T*>(g.C) + orow * g.ldc + n, v);
-      } else {
+      } else if constexpr (!kRanks) {
         if constexpr (EPI == EPI_GELU_T) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? quick_gelu_fast(v[e]) : quick_gelu_exact(v[e]);
         }
         store4<T>(reinterpret_cast<T*>(g.C) + orow * g.ldc + n, v);
       }
+    }
+  }
+  }  // pass
+  if constexpr (kRanks) {
+    // a row's count sits in the four lane groups of two waves (wn = 0, 1): fold the groups, then one integer atomic per wave
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      int c = cnt[i];
+      c += __shfl_xor(c, 16, 64);
+      c += __shfl_xor(c, 32, 64);
+      const int m = m0 + wm * TM + i * 16 + r;
+      if (q == 0 && m < g.M && c) atomicAdd(reinterpret_cast<int*>(g.C) + m, c);
     }
   }
 }
@@ -332,17 +396,47 @@ constexpr int piece_slot(int sched, int idx) {
   }
 }
 
-// The K loop is software pipelined: the MFMAs of a K-tile are issued in FM groups of 2*FN; the LDS reads of group
+// Issue slot of piece idx inside a K-step of `ng` MFMA groups: the schedules above name groups 0..2 of a full tile's 8; a
+// lower tile (HT, below) has 2, 4 or 6 groups and the hand-over sits in front of its last one, so slots are clamped to ng - 2.
+constexpr int piece_slot_in(int sched, int idx, int ng) {
+  const int s = piece_slot(sched, idx);
+  // (a piece issued after group u has the groups u + 1 .. ng - 2 to land before the hand-over waits for it: a K-step of 2 or 4
+  // groups has no such window - everything goes out in the hand-over, one whole K-step ahead)
+  return (s < 0 || ng < 6) ? -1 : (s > ng - 2 ? ng - 2 : s);
+}
+
+// wave-uniform q in 1..MAXQ: s_waitcnt vmcnt(BASE + PER * q) (the counter is an immediate: one compare + branch per value)
+template <int BASE, int PER, int MAXQ>
+__device__ __forceinline__ void wait_vmcnt_steps(int q) {
+  static_for<MAXQ>([&](auto I) {
+    constexpr int n = BASE + PER * (decltype(I)::value + 1);
+    if (q == decltype(I)::value + 1) wait_vmcnt<(n < 64 ? n : 63)>();
+  });
+}
+
+// The K loop is software pipelined: the MFMAs of a K-tile are issued in groups of 2*FN (one pair of 16-row fragments x
+// the wave's FN column fragments, per k-substep); the LDS reads of group
 // u+1 are issued before the MFMAs of group u (pinned with sched_group_barrier: hipcc otherwise sinks the reads next
 // to their first use), and the hand-over to the next K-tile (wait for its DMA, barrier, issue the DMA two tiles ahead,
 // first fragment reads) sits in front of the LAST group of the current tile, so neither LDS latency nor the barrier
 // leaves the matrix pipe idle.  The accumulators start from the bias slice (no bias registers in the epilogue).
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0, int ROT = 1, int SCHED = 0>
+//
+// HT > 0 (round 4; fp32): a TAIL of lower tiles.  fp32 is MFMA-bound on every CU, so with 256-row tiles a launch pays for whole
+// rounds of tiles over the CUs: out_proj of a 128-frame call (the reference's eval batch: 32 clips x 4 frames) has 297 tiles
+// for 256 CUs = 2 rounds for 1.16 rounds of work.  The host (gemm.hip) cuts the rows in a HEAD of g.hp 256-row panels whose
+// tiles fill whole rounds (walked in the panel-sharing order below) and a TAIL, the remaining rows, walked as tiles of
+// HT x 64 rows (HT = 1, 2, 3; XCD-major round robin, N fastest) by the same workgroups in the same launch: a tile of HT units
+// stages HT x 64 activation rows per K-step, each wave row takes 32 HT of them and the K-step issues 2 HT MFMA groups
+// instead of 8 - its cost is proportional to its height.  The tail's K-tiles are already streaming in while the last head
+// tile finishes.  An output element sees its K-tiles in the rotated order of its COLUMN tile and its products in the same
+// MFMA chain whatever the tile height: results are bit-identical to the fixed-tile kernels.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0, int ROT = 1, int SCHED = 0, int HT = 0>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const GemmArgs g) {
   constexpr int NW = WM * WN;
   constexpr int BKE = ROWB / (int)sizeof(T);
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int TN = BN / WN;
+  constexpr int FN = TN / 16;
+  constexpr int HQF = BM / 64;                        // 64-row units of a full tile; a wave row covers 32 rows of each
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int RG = (BM + BN) / 8;
   constexpr int LPW = RG / NW;
@@ -356,10 +450,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   constexpr int IPP = 16 / RPI;                       // store instructions per pass
   constexpr int OFF_STG = 2 * STAGE;                  // NW patches
   constexpr int OFF_BIAS = OFF_STG + NW * 2048;       // 2 x 1 KiB   (f32 outputs: a 16-row x 128-byte patch per wave as well)
-  constexpr int NST = kStaged ? FM * IPP : FM * FN;   // store instructions per wave per interior tile
+  constexpr int SPQ = 2 * (kStaged ? IPP : FN);       // store instructions per wave per 64-row unit of an interior tile
+  constexpr int NST = HQF * SPQ;                      // ... per full tile
+  static_assert(WM == 2 && BM % 64 == 0, "a tile is cut in 64-row units, 32 rows of each per wave row");
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
   static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4), "epilogue");
+  constexpr bool BAL = HT > 0;
+  static_assert(!BAL || (NW == 8 && BM == 256 && HT < HQF), "tail tiles: 8 waves, one LDS-DMA piece per wave and 64-row unit");
   // the counted wait behind the epilogue stores needs LPW + NST to fit the 6-bit vmcnt; tilings with more stores per wave
   // (4 waves of 128x128) wait for everything at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;
@@ -376,7 +474,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // smaller blocks / an N-split over XCD groups change the L2 re-fetch volume by up to -20 % but not the in-situ time
   // (the 4.7 MB c_fc weight and the ~6 live activation panels never fit a 4 MiB L2 together), so both default to off.
   const int tilesN = (g.N + BN - 1) / BN;
-  const int tilesM = (g.M + BM - 1) / BM;
+  const int tilesM = BAL ? g.hp : (g.M + BM - 1) / BM;   // panels of the head
   const int G = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
   const int nblk = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
   // N-split: the 8 XCDs form `ngrp` groups; a group only ever touches its own 1/ngrp of the N range, so only that part
@@ -389,25 +487,59 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   const int npanel = pq + (xi < pr ? 1 : 0);
   const int tnn = tilesN / ngrp, tn0 = grp * tnn;                          // N-tile range of this XCD's group
   const int nbw = (g.nblock > 0 && g.nblock < tnn) ? g.nblock : tnn;
-  const int t_begin = 0, t_end = npanel * tnn;  // local tile index inside the XCD's range
-  auto tile_coords = [&](int k, int& tm, int& tn) {
-    const int per_block = npanel * nbw;
-    const int nb = k / per_block, rem = k - nb * per_block;
-    const int wb = min(nbw, tnn - nb * nbw);
-    tm = mp0 + rem / wb;
-    tn = tn0 + nb * nbw + rem % wb;
+  // fp32 (kRR): tiles are dealt ROUND ROBIN - in round c, workgroup wk (XCD-major number) takes tile c G + wk of the N-fastest
+  // order, so the 32 workgroups of an XCD work on 32 consecutive tiles (they share ~32 / tilesN activation panels in their L2)
+  // and every workgroup gets the same number of tiles to within one.  (The panel-range partition above quantises PER XCD: 85
+  // panels of out_proj are 11 panels = 33 tiles for 32 workgroups on five of the XCDs - a second round for one tile.  bf16
+  // keeps it: there the chip is power- and bandwidth-limited and a partial round costs nothing measurable.)
+  constexpr bool kRR = sizeof(T) == 4 && ABL != 2;
+  const int qd_ = G >> 3, rd_ = G & 7;
+  const int wk = (xcd < rd_ ? xcd * (qd_ + 1) : rd_ * (qd_ + 1) + (xcd - rd_) * qd_) + pos;
+  // this workgroup's tiles, numbered 0 .. nh + ntw - 1: nh head tiles, then ntw tail tiles (tail tile numbers wk, wk + G, ...)
+  const int t_end = npanel * tnn;
+  const int head_tiles = tilesM * tilesN;
+  const int nh = kRR ? (wk < head_tiles ? (head_tiles - wk + G - 1) / G : 0)
+                     : (pos < t_end ? (t_end - pos + nblk - 1) / nblk : 0);
+  int ntw = 0;
+  if constexpr (BAL) {
+    const int rows = g.M - g.hp * BM;
+    const int ntail = rows > 0 ? ((rows + 64 * HT - 1) / (64 * HT)) * tilesN : 0;
+    ntw = wk < ntail ? (ntail - wk + G - 1) / G : 0;
+  }
+  const int cur_end = nh + ntw;
+  if (cur_end == 0) return;
+  // tile number `c` of this workgroup: first row, first column, height in 64-row units
+  auto tile_at = [&](int c, int& m0, int& n0, int& hq) {
+    if (!BAL || c < nh) {
+      if constexpr (kRR) {
+        const int lt = wk + c * G;
+        const int tm = lt / tilesN;
+        m0 = tm * BM;
+        n0 = (lt - tm * tilesN) * BN;
+      } else {
+        const int lt = pos + c * nblk;
+        const int per_block = npanel * nbw;
+        const int nb = lt / per_block, rem = lt - nb * per_block;
+        const int wb = min(nbw, tnn - nb * nbw);
+        m0 = (mp0 + rem / wb) * BM;
+        n0 = (tn0 + nb * nbw + rem % wb) * BN;
+      }
+      hq = HQF;
+    } else {
+      const int tt = wk + (c - nh) * G;
+      const int rt = tt / tilesN;
+      m0 = g.hp * BM + rt * (64 * HT);
+      n0 = (tt - rt * tilesN) * BN;
+      hq = HT;
+    }
   };
-  int t = t_begin + pos;
-  if (t >= t_end) return;
 
   // per-lane staging sources as 32-bit byte offsets from two (scalar) base pointers: the weight is < 4 GiB, the activations
   // are addressed from the first row of the current tile
   constexpr int LPA = BM / 8 / NW, LPB = BN / 8 / NW;  // LDS-DMA instructions per wave per stage for A / W
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must divide over the waves");
-  const int rin = lane >> 3, pc = lane & 7;
   // (row >> 1) & 7 of a staged row only depends on (wave, rin): row = (wave + i * NW) * 8 + rin and NW * 4 = 0 mod 8
   static_assert((NW * 4) % 8 == 0, "swizzle term must not depend on i");
-  const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
   unsigned offA[LPA], offB[LPB];
   const char* a_tile = reinterpret_cast<const char*>(g.A);  // 64-bit base of the current tile's first activation row (scalar)
   const int nk = g.K / BKE;
@@ -416,11 +548,20 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // instead of hammering the same lines in lockstep (+5..12 % on the K = 768 shapes).  rot only depends on the
   // N-tile, so a row's result still does not depend on the batch around it; gemm_kernel uses the same order.
   int rot = 0;
-  auto tile_sources = [&](int tile, int& m0, int& n0) {
-    int tm, tn;
-    tile_coords(tile, tm, tn);
-    m0 = tm * BM;
-    n0 = tn * BN;
+  int hq_ld = HQF;   // height (64-row units) of the tile whose K-tiles are being staged, and the fragment base of a wave in it
+  const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
+  int a_base_ld = (wm * 32 * HQF + r) * ROWB;
+  int cur = 0;       // number of the tile whose K-tiles are being staged
+  auto tile_sources = [&](int c, int& m0, int& n0) {
+    cur = c;
+    tile_at(c, m0, n0, hq_ld);
+    // (the staging rows are rebuilt from an opaque copy of the lane id: what is only needed here, once per tile, must not
+    // stay in registers - or in scratch - across the K loops)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    const int rin = lane_s >> 3, pc = lane_s & 7;
+    const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
+    a_base_ld = (wm * 32 * hq_ld + (lane_s & 15)) * ROWB;
     if constexpr (ROT == 1) rot = (n0 >> 8) % nk;  // a function of the output column block only
     // activation rows: a 64-bit tile base + 32-bit offsets inside the tile (the 4w-wide MLP rows of a 2048-frame fp32 pass are
     // 5 GB; the weight stays below 4 GiB)
@@ -438,15 +579,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
       offB[i] = (unsigned)gr * (unsigned)(g.ldw * (int)sizeof(T)) + swz;
     }
   };
+  // activation piece i of a wave covers rows (wave + i NW) 8 ..: unit i NW / 8 of the tile; a lower tile does not stage it
+  auto a_piece_staged = [&](int i) { return !BAL || (i * NW) / 8 < hq_ld; };
   auto stage_load = [&](int stage, int kt) {
     kt += rot;
     if (kt >= nk) kt -= nk;
     char* dst = smem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * ROWB)),
-          (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
+      if (a_piece_staged(i))
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * ROWB)),
+            (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
       __builtin_amdgcn_global_load_lds(
@@ -460,14 +604,16 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     kt += rot;
     if (kt >= nk) kt -= nk;
     char* dst = smem + stage * STAGE + wave * 1024;
-    if constexpr (idx < LPA)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * ROWB)),
-          (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
-    else
+    if constexpr (idx < LPA) {
+      if (a_piece_staged(idx))
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * ROWB)),
+            (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
+    } else {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[idx - LPA] + (unsigned)kt * ROWB)),
           (__attribute__((address_space(3))) void*)(dst + BM * ROWB + (idx - LPA) * NW * 1024), 16, 0, 0);
+    }
   };
   // SCHED > 0: the LDS-DMA pieces of the K-tile needed two steps ahead are not issued as one burst of LPW pieces inside
   // the hand-over; piece idx goes to slot piece_slot(SCHED, idx): -1 = still in the hand-over, u >= 0 = after MFMA
@@ -475,11 +621,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // Each piece blocks its wave's issue port for ~100 cycles, and right after the barrier the two waves of a SIMD would
   // both be in that burst, with nobody feeding the matrix pipe.
   static_assert(SCHED == 0 || LPW == 8, "piece schedules are written for 8 pieces per wave");
-  auto handover_pieces = [&](int stage, int kt) {
-    static_for<LPW>([&](auto I) {
-      if constexpr (piece_slot(SCHED, decltype(I)::value) < 0) stage_piece(stage, kt, I);
-    });
-  };
   auto bias_load = [&](int buf, int n0) {  // BN floats -> LDS by one LDS-DMA of wave 0 (part of that tile's first load)
     if (wave == 0) {
       const float* p = g.bias + min(n0 + lane * 4, g.N - 4);
@@ -489,48 +630,55 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     }
   };
 
-  const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
-  const int a_base = (wm * TM + r) * ROWB;
   const int b_base = BM * ROWB + (wn * TN + r) * ROWB;
 
   int m0, n0;
-  tile_sources(t, m0, n0);
+  tile_sources(0, m0, n0);
   bias_load(0, n0);
   stage_load(0, 0);
   stage_load(1, 1);
-  constexpr int NG = FM;        // MFMA groups per K-tile: 2 k-substeps x FM/2 row-tile pairs, 2*FN MFMAs each
-  constexpr int GPS = FM / 2;   // groups per k-substep
-  static_assert(FM % 2 == 0, "row tiles are consumed in pairs");
   int foff[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) foff[s] = ((((sizeof(T) == 2) ? (4 * s + q) : (q + 4 * s)) ^ f) * 16);
   FragT wb[2][FN], xp[2][2];
-  wait_vmcnt<LPW>();   // K-tile 0 of the first tile has landed (K-tile 1 may still be in flight)
+  // K-tile 0 of the first tile has landed (K-tile 1 may still be in flight: LPB + one piece per staged unit)
+  if constexpr (BAL) wait_vmcnt_steps<LPB, 1, HQF>(hq_ld); else wait_vmcnt<LPW>();  // (a workgroup may own tail tiles only)
   block_barrier();
 #pragma unroll
   for (int j = 0; j < FN; ++j) wb[0][j] = *reinterpret_cast<const FragT*>(smem + b_base + j * 16 * ROWB + foff[0]);
 #pragma unroll
-  for (int a = 0; a < 2; ++a) xp[0][a] = *reinterpret_cast<const FragT*>(smem + a_base + a * 16 * ROWB + foff[0]);
+  for (int a = 0; a < 2; ++a) xp[0][a] = *reinterpret_cast<const FragT*>(smem + a_base_ld + a * 16 * ROWB + foff[0]);
   int gbase = 0;            // global K-step counter at the start of the current tile (stage = step & 1)
   int it = 0;               // tile iteration (bias buffer = it & 1)
-  bool prev_counted = false;  // the previous tile issued exactly NST stores after its prefetches
+  int prev_counted = 0;     // > 0: the previous tile issued exactly prev_counted * SPQ stores after its prefetches
 
-  for (;;) {
+  // One output tile of HQ 64-row units: accumulators from the bias, the K loop, the epilogue.  Returns false after the last tile.
+  auto run_tile = [&](auto HQC) -> bool {
+    constexpr int HQ = decltype(HQC)::value;
+    constexpr int FMq = 2 * HQ;     // 16-row fragments per wave
+    constexpr int NG = FMq;         // MFMA groups per K-tile: 2 k-substeps x HQ row-fragment pairs, 2*FN MFMAs each
+    constexpr int GPS = HQ;         // groups per k-substep
+    constexpr int TMq = 32 * HQ;    // rows per wave row
     // the accumulators start from the bias slice of this tile (in LDS since the hand-over that published K-tile 0)
-    f32x4 acc[FM][FN];
+    f32x4 acc[FMq][FN];
     {
       const float* biasb = reinterpret_cast<const float*>(smem + OFF_BIAS + (it & 1) * 1024) + wn * TN + 4 * q;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(biasb + j * 16);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = b;
+        for (int i = 0; i < FMq; ++i) acc[i][j] = b;
       }
     }
 
     const int cm0 = m0, cn0 = n0;
-    const int tnext = t + nblk;
-    const bool has_next = tnext < t_end;
+    // (lane-derived addresses are rebuilt from an opaque copy of the lane id at every tile: hipcc would otherwise hoist the
+    // address arithmetic of the K loop AND of the epilogue in front of the tile loop and keep all of it alive across both)
+    int lane_k = lane;
+    asm volatile("" : "+v"(lane_k));
+    const int a_base = (wm * TMq + (lane_k & 15)) * ROWB;
+    const int tnext = cur + 1;
+    const bool has_next = tnext < cur_end;
 
     for (int kt = 0; kt < nk; ++kt) {
       const int sidx = (gbase + kt) & 1;
@@ -556,19 +704,30 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           // been issued; once they have returned the stage may be overwritten by the other waves' DMA.
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if constexpr (kCounted) {
-            if (kt == 0 && prev_counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
+            if (kt == 0 && prev_counted) {
+              if constexpr (BAL) wait_vmcnt_steps<0, SPQ, HQF>(prev_counted); else wait_vmcnt<NST>();
+            } else {
+              wait_vmcnt<0>();
+            }
           } else {
             wait_vmcnt<0>();
           }
           block_barrier();
           if (ABL != 1) {
             if (kt + 2 < nk) {
-              handover_pieces(sidx, kt + 2);
+              static_for<LPW>([&](auto I) {
+                if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) < 0) stage_piece(sidx, kt + 2, I);
+              });
             } else if (has_next) {
               if (kt + 2 == nk) {
                 tile_sources(tnext, m0, n0);
                 bias_load((it + 1) & 1, n0);
-                handover_pieces(sidx, 0);
+                // (the next tile may be of another height: its own hand-over share is decided by ITS group count, but
+                // what matters here is only that every piece of its K-tile 0 is issued exactly once: the pieces that
+                // do not go out here follow after this tile's groups in the last K-step, same predicate)
+                static_for<LPW>([&](auto I) {
+                  if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) < 0) stage_piece(sidx, 0, I);
+                });
               } else {
                 stage_load(sidx, 1);  // always a burst: it has to be older than the epilogue stores (counted vmcnt)
               }
@@ -580,10 +739,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           // (sched_group_barrier cannot order across blocks), and hipcc's lgkmcnt(0) for that MFMA's operands would wait
           // for their whole LDS latency with the matrix pipe idle - once per K-step
           const char* nx = smem + (sidx ^ 1) * STAGE;
+          const int a_nx = (BAL && last) ? a_base_ld : a_base;   // (the next K-tile may belong to the next tile)
 #pragma unroll
           for (int j = 0; j < FN; ++j) wb[0][j] = *reinterpret_cast<const FragT*>(nx + b_base + j * 16 * ROWB + foff[0]);
 #pragma unroll
-          for (int a = 0; a < 2; ++a) xp[0][a] = *reinterpret_cast<const FragT*>(nx + a_base + a * 16 * ROWB + foff[0]);
+          for (int a = 0; a < 2; ++a) xp[0][a] = *reinterpret_cast<const FragT*>(nx + a_nx + a * 16 * ROWB + foff[0]);
         }
         if constexpr (sizeof(T) == 4) {
           // fp32: a fragment pair is FOUR chained v_mfma_f32_16x16x4_f32 on one accumulator (40-cycle dependent latency
@@ -604,15 +764,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
             for (int j = 0; j < FN; ++j) mma<T>(wb[s & 1][j], xp[u & 1][a], acc[2 * p + a][j]);
         }
         if constexpr (SCHED > 0 && ABL != 1 && u + 1 < NG) {
-          constexpr bool any = piece_slot(SCHED, 0) == u || piece_slot(SCHED, 1) == u || piece_slot(SCHED, 2) == u ||
-                               piece_slot(SCHED, 3) == u || piece_slot(SCHED, 4) == u || piece_slot(SCHED, 5) == u ||
-                               piece_slot(SCHED, 6) == u || piece_slot(SCHED, 7) == u;
+          constexpr bool any = piece_slot_in(SCHED, 0, NG) == u || piece_slot_in(SCHED, 1, NG) == u || piece_slot_in(SCHED, 2, NG) == u ||
+                               piece_slot_in(SCHED, 3, NG) == u || piece_slot_in(SCHED, 4, NG) == u || piece_slot_in(SCHED, 5, NG) == u ||
+                               piece_slot_in(SCHED, 6, NG) == u || piece_slot_in(SCHED, 7, NG) == u;
           if constexpr (any) {
             // K-tile kt+1 (or K-tile 0 of the next output tile) into the stage the previous K-step has released
             if (kt > 0 && (kt + 1 < nk || has_next)) {
               const int lk = kt + 1 < nk ? kt + 1 : 0;
               static_for<LPW>([&](auto I) {
-                if constexpr (piece_slot(SCHED, decltype(I)::value) == u) stage_piece(sidx ^ 1, lk, I);
+                if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) == u) stage_piece(sidx ^ 1, lk, I);
               });
             }
           }
@@ -629,24 +789,27 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
         __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerGroup - 1, 0);
       });
     }
-    const bool interior = cm0 + BM <= g.M && cn0 + BN <= g.N;
+    const bool interior = cm0 + 64 * HQ <= g.M && cn0 + BN <= g.N;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int r = lane_e & 15, q = lane_e >> 4;   // (epilogue-local copies, see above)
     if constexpr (ABL == 3) {
       float keep = 0.f;
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FMq; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       if (keep == 123.456f) reinterpret_cast<float*>(g.C)[0] = keep;
-      prev_counted = false;
+      prev_counted = 0;
     } else {
       if constexpr (kStaged) {
         char* stg = smem + OFF_STG + wave * PATCH;
         char* wr = stg + r * ROWP + ((q & 1) << 3);
-        const int rrow = lane / CPR, rch = lane % CPR;
-        T* cbase = reinterpret_cast<T*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * g.ldc + cn0 + wn * TN + rch * 8;
+        const int rrow = lane_e / CPR, rch = lane_e % CPR;
+        T* cbase = reinterpret_cast<T*>(g.C) + (size_t)(cm0 + wm * TMq + rrow) * g.ldc + cn0 + wn * TN + rch * 8;
         const bool col_ok = cn0 + wn * TN + rch * 8 < g.N;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+        for (int i = 0; i < FMq; ++i) {
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
             f32x4 v = acc[i][j];
@@ -661,7 +824,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
             const int row = h * RPI + rrow;
             const bf16x8 val = *reinterpret_cast<const bf16x8*>(stg + row * ROWP + ((rch ^ (row & (CPR - 1))) << 4));
             T* p = cbase + (size_t)(i * 16 + h * RPI) * g.ldc;
-            if (interior || (cm0 + wm * TM + i * 16 + row < g.M && col_ok)) {
+            if (interior || (cm0 + wm * TMq + i * 16 + row < g.M && col_ok)) {
               // non-temporal: the tile is not read again by this kernel; a plain store write-allocates in L2 and evicts
               // the operand panels the other workgroups of the XCD are sharing (measured: operand re-fetch -35 %,
               // kernel +6..18 % on the N >= 2304 shapes)
@@ -675,20 +838,20 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
         // a private 16-row x 128-byte LDS patch (chunk ^ (row & 7) swizzle: conflict-free both ways) and leave as
         // 8 rows x 128 contiguous bytes per store instruction - the same number of store instructions (FM * FN).
         char* stg = smem + OFF_STG + wave * 2048;
-        const int rrow = lane >> 3, rch = lane & 7;
+        const int rrow = lane_e >> 3, rch = lane_e & 7;
         // EPI_RESID_F32 (C += acc + bias: the residual stream updated in place, so the LayerNorm behind the projection reads
         // ONE fp32 row instead of row + delta and writes no row back): every lane adds the 16 bytes of C it is about to
         // overwrite.  They are requested RWIN row-tiles ahead (RWIN * FN loads in flight per lane: the fragment registers
         // of the K loop are free here), whole lines per instruction like the stores, and non-temporal like them: the 1 GB
         // stream must not push the operand panels out of L2.
-        constexpr int RWIN = 4;
+        constexpr int RWIN = FMq < 4 ? FMq : 4;
         f32x4 xres[EPI == EPI_RESID_F32 ? RWIN : 1][FN / 2][2];
         auto resid_load = [&](int i, f32x4 (&dst)[FN / 2][2]) {
 #pragma unroll
           for (int jj = 0; jj < FN / 2; ++jj)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const int mo = cm0 + wm * TM + i * 16 + h * 8 + rrow, no = cn0 + wn * TN + jj * 32 + rch * 4;
+              const int mo = cm0 + wm * TMq + i * 16 + h * 8 + rrow, no = cn0 + wn * TN + jj * 32 + rch * 4;
               dst[jj][h] = f32x4{0.f, 0.f, 0.f, 0.f};
               if (interior || (mo < g.M && no < g.N))
                 dst[jj][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const TOUT*>(g.C) + (size_t)mo * g.ldc + no));
@@ -696,11 +859,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
         };
         if constexpr (EPI == EPI_RESID_F32) {
 #pragma unroll
-          for (int i = 0; i < RWIN && i < FM; ++i) resid_load(i, xres[i]);
+          for (int i = 0; i < RWIN; ++i) resid_load(i, xres[i]);
         }
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int m = cm0 + wm * TM + i * 16 + r;
+        for (int i = 0; i < FMq; ++i) {
+          const int m = cm0 + wm * TMq + i * 16 + r;
 #pragma unroll
           for (int jj = 0; jj < FN / 2; ++jj) {
 #pragma unroll
@@ -728,7 +891,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
               const int row = h * 8 + rrow;
               f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
               if constexpr (EPI == EPI_RESID_F32) val = xres[i % RWIN][jj][h] + val;
-              const int mo = cm0 + wm * TM + i * 16 + row, no = cn0 + wn * TN + jj * 32 + rch * 4;
+              const int mo = cm0 + wm * TMq + i * 16 + row, no = cn0 + wn * TN + jj * 32 + rch * 4;
               if (interior || (mo < g.M && no < g.N)) {
                 f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<TOUT*>(g.C) + (size_t)mo * g.ldc + no);
                 if constexpr (ABL == 4) *dst = val;  // lab: write-back instead of non-temporal stores
@@ -737,16 +900,26 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
             }
           }
           if constexpr (EPI == EPI_RESID_F32) {
-            if (i + RWIN < FM) resid_load(i + RWIN, xres[i % RWIN]);
+            if (i + RWIN < FMq) resid_load(i + RWIN, xres[i % RWIN]);
           }
         }
       }
-      prev_counted = interior;
+      prev_counted = interior ? HQ : 0;
     }
-    if (!has_next) break;
+    if (!has_next) return false;
     gbase += nk;
     ++it;
-    t = tnext;
+    return true;
+  };
+
+  // the head tiles, then the tail tiles: two loops, so that each body's address arithmetic is hoisted in front of ITS loop only
+  bool more = true;
+  if (!BAL || hq_ld == HQF) {
+    do more = run_tile(std::integral_constant<int, HQF>{});
+    while (more && (!BAL || hq_ld == HQF));
+  }
+  if constexpr (BAL) {
+    while (more) more = run_tile(std::integral_constant<int, HT>{});
   }
 }
 

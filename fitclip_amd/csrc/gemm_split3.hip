@@ -7,18 +7,6 @@ namespace fc {
 
 namespace {
 
-int cu_count() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return cus;
-}
-
 template <int EPI, int RW = 4>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = 3 * 512 * 96 + 2048;  // three stages (the epilogue borrows the released one) + two bias slices
@@ -29,7 +17,7 @@ int launch_one(const GemmArgs& a, hipStream_t stream) {
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split3: cannot raise dynamic LDS to %d bytes", lds);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, cu_count())), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), lds, stream, a);
   FC_CHECK_LAUNCH("gemm_split3");
   return FC_OK;
 }

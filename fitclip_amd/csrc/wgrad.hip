@@ -183,18 +183,6 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict
     *reinterpret_cast<f32x4*>(P + (size_t)chunk * cols + c) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-int num_cus_tn() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return cus;
-}
-
 struct TnPlan {
   bool big;
   int splits, rows_per_split, tiles;
@@ -205,7 +193,7 @@ TnPlan plan_tn(int M, int N1, int N2) {
   const int bn = p.big ? 256 : 128;
   p.tiles = ((N1 + bn - 1) / bn) * ((N2 + bn - 1) / bn);
   const int max_splits = std::max(1, M / (4 * TN_BK));
-  p.splits = std::max(1, std::min({max_splits, 64, (num_cus_tn() + p.tiles / 2) / p.tiles}));
+  p.splits = std::max(1, std::min({max_splits, 64, (device_cus() + p.tiles / 2) / p.tiles}));
   p.rows_per_split = ((M + p.splits - 1) / p.splits + TN_BK - 1) / TN_BK * TN_BK;
   p.splits = (M + p.rows_per_split - 1) / p.rows_per_split;
   return p;

@@ -62,6 +62,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_plan(M: int, N: int, K: int) -> "tuple[int, int]":
+    """(head_panels, tail_units): how the fp32 persistent GEMM cuts the rows of an [M, N] output over K columns on the current device -
+    256-row panels in whole tile rounds, then tiles of `tail_units` x 64 rows (0: none).  fc_gemm_plan."""
+    import ctypes as C
+    hp, ht = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.load().fc_gemm_plan(M, N, K, C.byref(hp), C.byref(ht)), "fc_gemm_plan")
+    return hp.value, ht.value
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype = torch.float32,
               gather: Optional[torch.Tensor] = None, row_stride: Optional[int] = None, rows: Optional[int] = None
               ) -> torch.Tensor:
@@ -276,6 +285,28 @@ def token_embedding_backward(ids: torch.Tensor, d_rows: torch.Tensor, vocab: int
         _lib.check(lib.fc_token_embedding_backward(ids.data_ptr(), d_rows.data_ptr(), out.data_ptr(), rows, D, vocab,
                                                    int(accumulate), scratch.data_ptr(), scratch.numel(),
                                                    _lib.current_stream()), "fc_token_embedding_backward")
+    return out
+
+
+def similarity_ranks(texts: torch.Tensor, videos: torch.Tensor, target_offset: int = 0,
+                     targets: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """ranks(similarity(texts, videos, alpha), target_offset) - or ranks_of(..., targets) - WITHOUT the [nt, nv] score matrix:
+    the comparison against the target column's score runs in the epilogue of the scoring GEMM (fc_similarity_ranks;
+    text_video_retrieval.py:70-80, metrics.py:16-20).  Identical ranks, ties included."""
+    _dev(texts, "texts", torch.float32), _dev(videos, "videos", torch.float32)
+    if texts.dim() != 2 or videos.dim() != 2 or texts.shape[1] != videos.shape[1]:
+        raise ValueError(f"similarity_ranks needs [nt, d] and [nv, d], got {tuple(texts.shape)} and {tuple(videos.shape)}")
+    nt, nv = texts.shape[0], videos.shape[0]
+    if targets is not None:
+        targets = _dev(targets.to(device=texts.device, dtype=torch.int32).contiguous(), "targets", torch.int32)
+        if targets.numel() != nt:
+            raise ValueError("one target per row")
+    out = torch.empty((nt,), dtype=torch.int32, device=texts.device)
+    if nt:
+        with torch.cuda.device(texts.device):
+            _lib.check(_lib.load().fc_similarity_ranks(texts.data_ptr(), videos.data_ptr(), nt, nv, texts.shape[1], alpha,
+                                                       target_offset, _ptr(targets), out.data_ptr(), _lib.current_stream()),
+                       "fc_similarity_ranks")
     return out
 
 

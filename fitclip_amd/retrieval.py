@@ -61,7 +61,7 @@ class TextVideoRetrievalModule(VideoTextModule):
         super().__init__(encoder, init_temperature, min_temperature)
         self.n_total = n_total
         self._outputs: List[TYPE_OUTPUT] = []
-        self._losses: List[Tuple[float, int]] = []
+        self._losses: List[Tuple[torch.Tensor, int]] = []
 
     def validation_step(self, batch: TYPE_INPUT) -> TYPE_OUTPUT:
         return self(batch)
@@ -72,7 +72,9 @@ class TextVideoRetrievalModule(VideoTextModule):
         and the epoch-level mean is all-reduced instead."""
         encoded_video, encoded_text = output
         loss = ops.nce_loss(self.step_scores(encoded_video, encoded_text))
-        self._losses.append((float(loss), len(encoded_video)))
+        # (the loss stays on the device until the epoch ends, as Lightning's `self.log` keeps it: a `float()` here would drain
+        # the stream after every 32-clip batch)
+        self._losses.append((loss, len(encoded_video)))
         self._outputs.append(output)
         return output
 
@@ -85,8 +87,9 @@ class TextVideoRetrievalModule(VideoTextModule):
         n_total = self.n_total if self.n_total is not None else len(encoded_videos) * world_size
         metrics = D.sharded_retrieval(encoded_videos, encoded_texts, n_total, ops.similarity,
                                       lambda s, off: ops.ranks(s, off))
-        num = torch.tensor([sum(l * b for l, b in self._losses), float(sum(b for _, b in self._losses))],
-                           dtype=torch.float64, device=encoded_videos.device)
+        losses = torch.stack([torch.as_tensor(l, device=encoded_videos.device).reshape(()) for l, _ in self._losses]).double()
+        sizes = torch.tensor([float(b) for _, b in self._losses], dtype=torch.float64, device=encoded_videos.device)
+        num = torch.stack([(losses * sizes).sum(), sizes.sum()])
         if D.collectives_active():
             torch.distributed.all_reduce(num)
         metrics["loss/val"] = float(num[0] / num[1])

@@ -138,6 +138,14 @@ FC_API int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb,
                   int32_t ldo, fc_stream stream);
 FC_API int fc_ranks(const float* scores, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t target_offset, int32_t* ranks,
              fc_stream stream);
+/* Scoring WITHOUT the score matrix ("compute ranks tile-wise"; aligner/text_video_retrieval.py:70-80 +
+ * aligner/metrics.py:16-20): ranks[i] = position of column t_i (= targets ? targets[i] : i + target_offset, clamped) in the
+ * stable descending order of row i of alpha * T @ V^T, T [nt, dim], V [nv, dim], dim % 32 == 0.  The comparison runs in the
+ * epilogue of the exact-fp32 scoring GEMM; every score has the bits fc_similarity would store, so the ranks equal
+ * fc_similarity + fc_ranks / fc_ranks_of exactly (ties included) while nothing of size nt x nv touches memory
+ * (8192 x 8192: 268 MB).  ranks: int32 [nt], overwritten. */
+FC_API int fc_similarity_ranks(const float* T, const float* V, int32_t nt, int32_t nv, int32_t dim, float alpha,
+                        int32_t target_offset, const int32_t* targets, int32_t* ranks, fc_stream stream);
 /* Zero-shot classification (aligner/video_text_classification.py): fc_ranks_of = rank of the label
  * column targets[i] in row i (Accuracy@k = rank < k, MedianRank); fc_group_mean = mean over the `group` template
  * prompts of each label (:88-90), out [n_groups, dim]. */
@@ -159,6 +167,12 @@ FC_API int fc_wise(const float* a, const float* b, double weight_for_2, float* o
 FC_API int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const void* W, const float* bias, void* C,
             const float* aux, float alpha, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
             int32_t P, int32_t tile, fc_stream stream);
+/* How the fp32 persistent GEMM cuts the rows of an [M, N] output over K columns on the current device: `head_panels` 256-row panels whose
+ * tiles fill whole rounds over the compute units, then a tail of tiles of `tail_units` x 64 rows (0: no tail) in the same
+ * launch.  fc_gemm's `tile`: 0 auto, 1 / 2 one 128 x 128 / 256 x 256 tile per workgroup, 3 persistent with this cut,
+ * 4 persistent with whole 256-row tiles only, 5..7 persistent with a tail of 1..3 units forced (tests).  Results do not
+ * depend on the cut or the kernel. */
+FC_API int fc_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t* head_panels, int32_t* tail_units);
 FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather, const float* gamma, const float* beta,
                  void* y, int64_t y_stride, int32_t out_kind, int32_t rows, int32_t D, fc_stream stream);
 /* v = x[r] + delta[r]; if write_x: x[r] = v; y[i] = LayerNorm(v) * gamma + beta, r = gather ? gather[i] : i.  The

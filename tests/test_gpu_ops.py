@@ -70,6 +70,34 @@ def test_gemm_all_epilogues(M, N, K, tile, dtype):
         assert _rel(out.view(4, P + 1, N), want) < 2e-6
 
 
+# the reference's eval batch (32 clips x 4 frames = 128 frames = 25 216 token rows) at the three output widths of a block: on
+# 256 compute units the planner picks a tail of 1, 2 and 3 units for them; 25 179 rows end inside a 64-row unit
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 2304, 768), (25216, 3072, 768), (25179, 768, 3072),
+                                   (900, 768, 256), (70000, 512, 192)])
+def test_pipelined_gemm_row_cut_is_bit_invisible(M, N, K):
+    """The persistent fp32 GEMM cuts its rows into a head of whole rounds of 256-row tiles and a tail of 64 / 128 / 192-row
+    tiles (csrc/gemm_kernel.h, HT): every forced cut, the planned one and the one-tile-per-workgroup kernels must produce the
+    SAME BITS for all three block epilogues - an output element sees its K-tiles and its MFMA chain in the same order whatever
+    tile it falls into."""
+    a, w, bias = _rand(M, K, seed=11).to(DEV), _rand(N, K, seed=12, scale=K ** -0.5).to(DEV), _rand(N, seed=13).to(DEV)
+    resid = _rand(M, N, seed=14).to(DEV)
+    hp, ht = ops.gemm_plan(M, N, K)
+    assert 0 <= hp <= (M + 255) // 256 and 0 <= ht <= 3
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256 and M == 25216:
+        assert (hp, ht) == {768: (85, 1), 2304: (85, 2), 3072: (85, 3)}[N]  # (K = 768)
+    for epi in (ops.EPI_BIAS_T, ops.EPI_GELU_T, ops.EPI_RESID_F32):
+        def run(tile):
+            out = resid.clone() if epi == ops.EPI_RESID_F32 else None
+            return ops.gemm(a, w, bias, epi, out=out, tile=tile)
+        want = run(2)
+        if M <= 1000:  # (small enough for float64 on the host: the plain kernel itself against the definition)
+            z = a.double().cpu() @ w.double().cpu().T + bias.double().cpu()
+            ref = {ops.EPI_BIAS_T: z, ops.EPI_GELU_T: z * torch.sigmoid(1.702 * z), ops.EPI_RESID_F32: resid.double().cpu() + z}[epi]
+            assert _rel(want, ref) < 5e-6
+        for tile in (3, 4, 5, 6, 7, 1):
+            assert torch.equal(run(tile), want), (epi, tile)
+
+
 def test_gemm_rejects_bad_arguments():
     from fitclip_amd._lib import FitclipHipError
     a, w = torch.zeros(8, 48, device=DEV), torch.zeros(8, 48, device=DEV)
@@ -161,6 +189,28 @@ def test_similarity_ranks_and_losses():
         assert abs(float(ops.nce_loss(a.to(DEV))) - float(O.nce_loss(a.double()))) < 1e-4 * max(1, scale)
         kd, ref = float(ops.teacher_student_nce_loss(a.to(DEV), b.to(DEV))), float(O.teacher_student_nce_loss(a.double(), b.double()))
         assert abs(kd - ref) < 2e-5 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("nt,nv,dim,offset", [(5, 5, 32, 0), (300, 1000, 512, 100), (129, 257, 64, 7), (1000, 1000, 512, 0),
+                                              (64, 4099, 512, 2000)])
+def test_similarity_ranks_equal_the_materialised_path(nt, nv, dim, offset):
+    """fc_similarity_ranks (ranks from the scoring GEMM's epilogue, no [nt, nv] matrix) against fc_similarity + fc_ranks /
+    fc_ranks_of: IDENTICAL ranks, with exact ties - duplicated video rows, and embeddings of small integers whose scores are
+    exact in fp32 - deciding many positions (metrics.py:16-20: stable order, a tie goes to the lower column)."""
+    g = torch.Generator().manual_seed(nt * 7 + nv)
+    t = torch.randn(nt, dim, generator=g)
+    v = torch.randn(nv, dim, generator=g)
+    v[::3] = v[1:2]                                  # every third video is the SAME row: exact ties in every text row
+    ti, vi = torch.randint(-2, 3, (nt, dim), generator=g).float(), torch.randint(-2, 3, (nv, dim), generator=g).float()
+    for tt, vv, alpha in ((t, v, 1.0), (ti, vi, 1.0), (t, v, 66.666)):
+        td, vd = tt.to(DEV), vv.to(DEV)
+        scores = ops.similarity(td, vd, alpha=alpha)
+        assert ops.similarity_ranks(td, vd, offset, alpha=alpha).tolist() == ops.ranks(scores, offset).tolist()
+        tgt = torch.randint(0, nv, (nt,), generator=g)
+        assert ops.similarity_ranks(td, vd, targets=tgt, alpha=alpha).tolist() == ops.ranks_of(scores, tgt).tolist()
+    # and against the oracle on the integer case (scores exact in fp32: no arithmetic to argue about)
+    want = O.ranks_of_target(ti @ vi.T, (torch.arange(nt) + offset).clamp(max=nv - 1))
+    assert ops.similarity_ranks(ti.to(DEV), vi.to(DEV), offset).tolist() == want.tolist()
 
 
 def test_loss_matches_reference_fixture(golden_dir):
