@@ -376,7 +376,8 @@ def run_mode(precision, sd, video, text, args, shards, device, backend, full_det
         ms, cnt, flops = by_kernel[dom_key]
         timing_source, ref_elapsed_ms = "hipEvent pairs in the instrumented extra step", split_elapsed * 1e3
     epi, N, K, M, tile = dom_key
-    kname = {1: "gemm_kernel<128x128>", 2: "gemm_kernel<256x256>", 3: "gemm_pipelined_kernel<256x256>"}.get(tile, "gemm")
+    kname = {1: "gemm_kernel<128x128>", 2: "gemm_kernel<256x256>", 3: "gemm_pipelined_kernel<256x256>",
+             8: "gemm_kernel<64x64, 4-stage ring>"}.get(tile, "gemm")
     peak = PEAK_TFLOPS[precision]
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, traffic_note = load_traffic(precision, (M, N, K), EPI_NAMES[epi])
@@ -661,7 +662,8 @@ def run_wise_config(dims, args, shards, device, backend):
     if tile == 3:
         from fitclip_amd import ops
         hp, ht = ops.gemm_plan(M, N, K)
-    kname = {1: "gemm_kernel<128x128>", 2: "gemm_kernel<256x256>", 3: "gemm_pipelined_kernel<256x256>"}.get(tile, "gemm")
+    kname = {1: "gemm_kernel<128x128>", 2: "gemm_kernel<256x256>", 3: "gemm_pipelined_kernel<256x256>",
+             8: "gemm_kernel<64x64, 4-stage ring>"}.get(tile, "gemm")
     traffic, traffic_note = load_traffic("fp32", (M, N, K), EPI_NAMES[epi])
     out["roofline"] = {"bound": "mfma", "kernel": f"{kname}<fp32,{EPI_NAMES[epi]}> M={M} N={N} K={K}",
                        "achieved": round(kflops / (ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",

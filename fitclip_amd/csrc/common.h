@@ -99,7 +99,7 @@ struct GemmArgs {
   int tgt_off, ctw;
 };
 
-// tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = persistent pipelined, 4..7 = pipelined with a forced row cut (gemm.hip)
+// tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = persistent pipelined, 4..7 = pipelined with a forced row cut, 8 = 64x64 on a four-stage ring (gemm.hip)
 int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStream_t stream);
 // split-fp32 GEMM over three-plane operands (gemm_split3.h).  a.K counts fp32 columns; a.lda / a.ldw count bf16 positions of
 // the x3 rows (>= 4 K); a.ldc counts floats (EPI_BIAS_F32) or bf16 positions of the x3 output rows (EPI_GELU_X3, >= 4 N)

@@ -7,10 +7,10 @@ namespace fc {
 
 namespace {
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int NSTG = 2>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * (BM + BN) * ROWB;
-  auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI>;
+  constexpr int lds = NSTG * (BM + BN) * ROWB;
+  auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI, 0, NSTG>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", lds);
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
@@ -108,21 +108,30 @@ bool pipelined_ok(const GemmArgs& a) {
          (size_t)a.N * a.ldw * esz < (1ull << 32);
 }
 
+constexpr bool small_ring_epilogue(int epi) { return epi == EPI_BIAS_T || epi == EPI_GELU_T || epi == EPI_RESID_F32; }
+
 template <typename T>
 int resolve_tile(int epi, const GemmArgs& a, int tile) {
   if (tile != 0) return tile;
   const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || epi == EPI_RESID_F32 || (epi == EPI_DGELU_T && sizeof(T) == 4);
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
+  // small fp32 block GEMMs (the text tower of an eval batch: 32 captions = 2464 rows, the N = 512 projections 80 tiles of
+  // 128 x 128 for 256 CUs): 64 x 64 tiles on a four-stage ring (gemm_kernel.h, NSTG) while the 128 x 128 tiles would not fill
+  // 2.5 rounds.  tools/text_gemm_probe.py, us per launch 128 x 128 -> ring: 32 captions out_proj 39 -> 22, c_proj 136 -> 76, c_fc
+  // 75 -> 55, QKV 43 -> 44; 128 captions out_proj 76 -> 53, c_proj 267 -> 199 (QKV / c_fc run on the pipelined kernel there)
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (sizeof(T) == 4 && small_ring_epilogue(epi) && 2 * t128 < 5 * (long)device_cus()) return 8;
   return t256 >= 512 ? 2 : 1;
 }
 
 // tile: 0 = auto, 1 = 128x128 plain, 2 = 256x256 plain, 3 = 256x256 persistent + pipelined (the block epilogues); 4..7 = the
-// pipelined kernel with its fp32 row cut forced: 4 = whole tiles only, 5..7 = a tail of 1..3 x 64-row tiles
+// pipelined kernel with its fp32 row cut forced: 4 = whole tiles only, 5..7 = a tail of 1..3 x 64-row tiles; 8 = 64 x 64 tiles on
+// a four-stage ring (fp32 block epilogues, small problems)
 template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
-  const int forced_ht = tile >= 4 ? tile - 4 : -1;
-  if (tile >= 4) tile = 3;
+  const int forced_ht = tile >= 4 && tile <= 7 ? tile - 4 : -1;
+  if (tile >= 4 && tile <= 7) tile = 3;
   constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
@@ -134,6 +143,10 @@ int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     }
   }
   if (tile == 2) return launch_one<T, 256, 256, 2, 4, EPI>(a, stream);
+  if (tile == 8) {
+    if constexpr (sizeof(T) == 4 && small_ring_epilogue(EPI)) return launch_one<T, 64, 64, 2, 2, EPI, 4>(a, stream);
+    else return fail(FC_EINVAL, "gemm: the 64 x 64 ring kernel serves the fp32 block epilogues");
+  }
   return launch_one<T, 128, 128, 2, 2, EPI>(a, stream);
 }
 
@@ -190,7 +203,7 @@ int launch_similarity_ranks(const float* T, const float* V, int nt, int nv, int 
 }
 
 int gemm_resolved_tile(int precision, int epilogue, const GemmArgs& a, int tile) {
-  if (tile >= 4) tile = 3;
+  if (tile >= 4 && tile <= 7) tile = 3;
   return precision == PREC_BF16 ? resolve_tile<bf16>(epilogue, a, tile) : resolve_tile<float>(epilogue, a, tile);
 }
 
@@ -214,7 +227,7 @@ int launch_gemm(int precision, int epilogue, const GemmArgs& a, int tile, hipStr
         G * G != a.P || a.K != 3 * a.gP * a.gP)
       return fail(FC_EINVAL, "gemm: patch gather needs the f32 patch-embed epilogue, patch %% 4 == 0 and K = 3 p^2");
   }
-  if (tile < 0 || tile > 7) return fail(FC_EINVAL, "gemm: tile=%d", tile);
+  if (tile < 0 || tile > 8) return fail(FC_EINVAL, "gemm: tile=%d", tile);
   return precision == PREC_BF16 ? launch_epi<bf16>(epilogue, a, tile, stream)
                                 : launch_epi<float>(epilogue, a, tile, stream);
 }

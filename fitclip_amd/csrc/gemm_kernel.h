@@ -92,9 +92,41 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const f32x4& v
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& body) {
+  if constexpr (I < N) {
+    body(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(body);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// wave-uniform q in 1..MAXQ: s_waitcnt vmcnt(BASE + PER * q) (the counter is an immediate: one compare + branch per value)
+template <int BASE, int PER, int MAXQ>
+__device__ __forceinline__ void wait_vmcnt_steps(int q) {
+  static_for<MAXQ>([&](auto I) {
+    constexpr int n = BASE + PER * (decltype(I)::value + 1);
+    if (q == decltype(I)::value + 1) wait_vmcnt<(n < 64 ? n : 63)>();
+  });
+}
+
 // ABL (tools/gemm_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 2 = every block stages tile (0,0);
 // 3 = no epilogue stores; 4 = (f32, pipelined) write-back instead of non-temporal epilogue stores.
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0>
+// NSTG > 2: a ring of NSTG LDS stages with the LDS-DMA NSTG - 1 K-tiles ahead (counted vmcnt, one raw barrier per K-step) - for
+// SMALL tiles on small problems: the text tower of a 32-caption eval batch is 2464 rows; its N = 512 GEMMs are 80 tiles of
+// 128 x 128 for 256 CUs, and a 64 x 64 tile's K-step is 0.4 us of MFMA issue - with two stages every K-step waits for the
+// latency of its own loads.  Same K order and MFMA chain per output element as every other kernel of this file.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ABL = 0, int NSTG = 2>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   constexpr int NW = WM * WN;
   constexpr int BKE = ROWB / (int)sizeof(T);  // K elements per tile row
@@ -212,12 +244,27 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
   const int rot = kBiasInit ? (n0 >> 8) % nk : 0;
   auto krot = [&](int kt) { return kt + rot >= nk ? kt + rot - nk : kt + rot; };
   if constexpr (kRanks) __syncthreads();  // (every wave has left the previous pass's last stage)
-  stage_load(0, krot(0));
+  static_assert(NSTG >= 2 && (NSTG == 2 || (NSTG - 2) * LPW < 64), "ring depth");
+  if constexpr (NSTG == 2) {
+    stage_load(0, krot(0));
+  } else {
+#pragma unroll
+    for (int p = 0; p < NSTG - 1; ++p)
+      if (p < nk) stage_load(p, krot(p));
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ABL != 1 && kt + 1 < nk) stage_load((kt + 1) & 1, krot(kt + 1));
-    const char* st = smem + (kt & 1) * STAGE;
+    if constexpr (NSTG == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ABL != 1 && kt + 1 < nk) stage_load((kt + 1) & 1, krot(kt + 1));
+    } else {
+      // K-tile kt has landed when at most the K-tiles behind it are in flight: NSTG - 2 of them, fewer at the end of the row
+      const int behind = min(NSTG - 2, nk - 1 - kt);
+      if (behind > 0) wait_vmcnt_steps<0, LPW, NSTG - 2>(behind); else wait_vmcnt<0>();
+      block_barrier();  // ... for every wave; and every wave has finished reading the stage of K-tile kt - 1
+      if (ABL != 1 && kt + NSTG - 1 < nk) stage_load((kt + NSTG - 1) % NSTG, krot(kt + NSTG - 1));
+    }
+    const char* st = smem + (kt % NSTG) * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int c = (sizeof(T) == 2) ? (4 * s + q) : (q + 4 * s);
@@ -357,25 +404,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs g) {
 //     arrives by LDS-DMA with the first K-tile (an ordinary global load here would make hipcc drain vmcnt to 0);
 //   * barriers are raw `s_barrier`s with hand-placed waits (a `__syncthreads()` would add `vmcnt(0)`).
 // Supported epilogues: EPI_BIAS_T, EPI_GELU_T (the four big GEMMs of a transformer block).  Needs K/BKE >= 3.
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& body) {
-  if constexpr (I < N) {
-    body(std::integral_constant<int, I>{});
-    static_for<N, I + 1>(body);
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void block_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 // Issue slot of LDS-DMA piece idx (0..3 activation rows, 4..7 weight rows) under schedule `sched`; see the kernel.
 constexpr int piece_slot(int sched, int idx) {
   switch (sched) {
@@ -403,15 +431,6 @@ constexpr int piece_slot_in(int sched, int idx, int ng) {
   // (a piece issued after group u has the groups u + 1 .. ng - 2 to land before the hand-over waits for it: a K-step of 2 or 4
   // groups has no such window - everything goes out in the hand-over, one whole K-step ahead)
   return (s < 0 || ng < 6) ? -1 : (s > ng - 2 ? ng - 2 : s);
-}
-
-// wave-uniform q in 1..MAXQ: s_waitcnt vmcnt(BASE + PER * q) (the counter is an immediate: one compare + branch per value)
-template <int BASE, int PER, int MAXQ>
-__device__ __forceinline__ void wait_vmcnt_steps(int q) {
-  static_for<MAXQ>([&](auto I) {
-    constexpr int n = BASE + PER * (decltype(I)::value + 1);
-    if (q == decltype(I)::value + 1) wait_vmcnt<(n < 64 ? n : 63)>();
-  });
 }
 
 // The K loop is software pipelined: the MFMAs of a K-tile are issued in groups of 2*FN (one pair of 16-row fragments x

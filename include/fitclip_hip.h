@@ -170,8 +170,9 @@ FC_API int fc_gemm(int32_t precision, int32_t epilogue, const void* A, const voi
 /* How the fp32 persistent GEMM cuts the rows of an [M, N] output over K columns on the current device: `head_panels` 256-row panels whose
  * tiles fill whole rounds over the compute units, then a tail of tiles of `tail_units` x 64 rows (0: no tail) in the same
  * launch.  fc_gemm's `tile`: 0 auto, 1 / 2 one 128 x 128 / 256 x 256 tile per workgroup, 3 persistent with this cut,
- * 4 persistent with whole 256-row tiles only, 5..7 persistent with a tail of 1..3 units forced (tests).  Results do not
- * depend on the cut or the kernel. */
+ * 4 persistent with whole 256-row tiles only, 5..7 persistent with a tail of 1..3 units forced (tests), 8 one 64 x 64 tile
+ * per workgroup on a four-stage LDS ring (what small fp32 problems resolve to).  Results do not depend on the cut or the
+ * kernel. */
 FC_API int fc_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t* head_panels, int32_t* tail_units);
 FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather, const float* gamma, const float* beta,
                  void* y, int64_t y_stride, int32_t out_kind, int32_t rows, int32_t D, fc_stream stream);

@@ -50,7 +50,7 @@ def test_gemm_all_epilogues(M, N, K, tile, dtype):
         assert _rel(acc, resid.double() + z) < 2e-6
         if dtype == torch.float32:
             assert torch.equal(acc, resid.to(DEV) + ops.gemm(ad, wd, bd, ops.EPI_BIAS_T, tile=3))
-        for other in (1, 2):
+        for other in (1, 2) + ((8,) if dtype == torch.float32 else ()):  # (8: 64 x 64 tiles on a four-stage ring, fp32)
             acc2 = resid.to(DEV).clone()
             ops.gemm(ad, wd, bd, ops.EPI_RESID_F32, out=acc2, tile=other)
             assert torch.equal(acc2, acc)
@@ -94,7 +94,7 @@ def test_pipelined_gemm_row_cut_is_bit_invisible(M, N, K):
             z = a.double().cpu() @ w.double().cpu().T + bias.double().cpu()
             ref = {ops.EPI_BIAS_T: z, ops.EPI_GELU_T: z * torch.sigmoid(1.702 * z), ops.EPI_RESID_F32: resid.double().cpu() + z}[epi]
             assert _rel(want, ref) < 5e-6
-        for tile in (3, 4, 5, 6, 7, 1):
+        for tile in (3, 4, 5, 6, 7, 1, 8):
             assert torch.equal(run(tile), want), (epi, tile)
 
 
