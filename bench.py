@@ -541,20 +541,37 @@ def run_kd_config(sd, dims, args, shards, device, backend):
     student = ClipVideoTextEncoder(build_clip(synth.perturbed_state_dict(sd, dims, seed=5, rel=0.05), precision="fp32",
                                               device=device), num_frames=frames)
     teacher = ClipVideoTextEncoder(build_clip(sd, precision="fp32", device=device), num_frames=frames)
-    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=3e-7)
+    # (activation arenas of at most 512 frames = 60 GB each: a share that is split below keeps several of them)
+    module = TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=3e-7, max_frames_per_pass=512)
     n_lab = n // 2
     batch = {"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
              "text_teacher": {"input_ids": ids}, "dataset": ["labeled"] * n_lab + ["unlabeled"] * (n - n_lab)}
+    # A rank's share keeps 116 MB of activations per frame (nothing is recomputed): 64 clips x 8 frames = 65 GB fit, the 512 or
+    # 256 clips of one or two ranks do not.  The step is then SPLIT (training.py: split_step): as many clips as fit next to one
+    # micro-batch keep their activations, the others are forwarded without them and re-forwarded micro-batch by micro-batch in
+    # the backward (gradients accumulated; same loss bit for bit).  Sized from the memory that is free now.
+    torch.cuda.empty_cache()
+    keep, micro = module.plan_split(n, frames, micro_clips=args.micro_clips) if args.keep_clips is None else (args.keep_clips, args.micro_clips)
+    if keep < n:
+        module.split_step(keep, micro)
     losses = [module.fit_step(batch) for _ in range(args.warmup)]
     elapsed, last = timed_steps(lambda: losses.append(module.fit_step(batch)), args.steps, device, backend)
     n_big = max(shards.counts)
-    flops = 3.0 * n_big * (frames * GF_PER_FRAME + GF_PER_TEXT) + (n_big - n_big // 2) * (frames * GF_PER_FRAME + GF_PER_TEXT)
+    pair = frames * GF_PER_FRAME + GF_PER_TEXT
+    flops = 3.0 * n_big * pair + (n_big - n_big // 2) * pair
+    executed = flops + max(0, n_big - keep) * pair if keep < n else flops   # + the second student forward of the clips not kept
     tf = flops * args.steps / elapsed / 1e12
     return {"value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "roofline": {"bound": "mfma", "kernel": "whole training step of the largest shard (forward, dgrad, wgrad, teacher forward)",
                          "achieved": round(tf, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
                          "frac": round(tf / PEAK_TFLOPS["fp32"], 4), "traffic": None,
-                         "flops_per_step": flops, "timing": "wall time of the timed region, max over ranks"},
+                         "flops_per_step": flops, "executed_flops_per_step": executed,
+                         "executed_frac": round(executed * args.steps / elapsed / 1e12 / PEAK_TFLOPS["fp32"], 4),
+                         "timing": "wall time of the timed region, max over ranks"},
+            "split_step": ({"kept_clips": keep, "micro_batch_clips": micro, "recomputed_clips": n - keep,
+                            "note": "activations of the whole share do not fit: gradient-cache schedule, one more student "
+                                    "forward over the clips that were not kept (counted in executed_flops_per_step only)"}
+                           if keep < n else None),
             "losses": [round(float(x), 6) for x in losses],
             "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
@@ -710,6 +727,9 @@ def main() -> None:
                          "training step in total, sharded; strong)")
     ap.add_argument("--total-clips", type=int, default=None, help="c3 / c4 / c5: clips over ALL ranks (default 4096 / 8192 / 512)")
     ap.add_argument("--eval-batch", type=int, default=None, help="c3 / c4: clips per encoder call (default 32 / 128)")
+    ap.add_argument("--micro-clips", type=int, default=32, help="c5: clips per micro-batch when a rank's share does not fit (split step)")
+    ap.add_argument("--keep-clips", type=int, default=None,
+                    help="c5: clips whose activations are kept (default: as many as fit, from the free device memory)")
     ap.add_argument("--all-legs", action="store_true",
                     help="with more than one rank, also run the secondary legs (bf16_mode, fp32_split_mode); default: headline only")
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"],
@@ -806,7 +826,8 @@ def main() -> None:
                              "weights": "random init (seed 42) teacher, student = teacher perturbed by 5 %; AdamW lr 3e-7",
                              "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
                              "collectives": collectives},
-                  "roofline": kd["roofline"], "losses": kd["losses"], "peak_memory_gb": kd["peak_memory_gb"]}
+                  "roofline": kd["roofline"], "split_step": kd["split_step"], "losses": kd["losses"],
+                  "peak_memory_gb": kd["peak_memory_gb"]}
         if rank == 0:
             print(json.dumps(result), flush=True)
         if grouped:

@@ -248,6 +248,11 @@ class TeacherStudentTrainer(TeacherStudentModule):
         self.scale_v = torch.zeros(4, dtype=torch.float32, device=dev)
         self._pending: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self.last_losses: Dict[str, float] = {}
+        # Local batches whose activations do not fit the device (BASELINE configs[4] on one or two GPUs: 512 clips x 8 frames keep
+        # 116 MB per frame = 476 GB): `split_step(keep_clips, micro_clips)` - see `_student_forward`.
+        self.keep_clips: Optional[int] = None
+        self.micro_clips: Optional[int] = None
+        self._split: Optional[Dict[str, Any]] = None
 
     # ------------------------------------------------------------------------------------------------ training_step
     def training_step(self, batch: Mapping[str, Any]) -> Dict[str, Tuple[Tuple[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]]:
@@ -270,7 +275,7 @@ class TeacherStudentTrainer(TeacherStudentModule):
             text_student = replace(text_student, self.tokenized_prompts)
             text_teacher = replace(text_teacher, self.teacher_tokenized_prompts)
             text_lengths[idx] = self.tokenized_prompts.shape[0]
-        sv, st = self.student.forward(batch["video_student"], {"input_ids": text_student})
+        sv, st = self._student_forward(batch["video_student"], text_student)
         with torch.no_grad():
             if self.teacher_on_labeled:
                 tv, tt = self.teacher(video=batch["video_teacher"], text={"input_ids": text_teacher})
@@ -303,6 +308,56 @@ class TeacherStudentTrainer(TeacherStudentModule):
             v0, t0 = v0 + nv, t0 + nt
         self._rows = (v0, t0)
         return out
+
+    # ------------------------------------------------------------------------------------- a batch larger than memory
+    def split_step(self, keep_clips: Optional[int], micro_clips: Optional[int]) -> None:
+        """The contrastive losses couple every row of the batch, so a local batch cannot simply be cut into independent
+        training steps.  With `micro_clips` set, a step runs as (the gradient-cache schedule):
+          1. student forward of the first `keep_clips` clips WITH kept activations, of the other clips WITHOUT (the inference
+             forward, in micro-batches) - embeddings are bit-invariant to the batch they are computed in, so the embedding
+             matrix, the loss and its gradient w.r.t. the embeddings are exactly those of the unsplit step;
+          2. backward of the kept part; then per micro-batch of `micro_clips` clips: forward again with kept activations,
+             backward with its rows of the embedding gradient, parameter gradients ACCUMULATED; the gradient exchange with
+             the other ranks happens once, in the last backward.
+        Cost: one more student forward over the clips that were not kept.  `micro_clips=None` restores the plain step."""
+        if micro_clips is not None and micro_clips <= 0:
+            raise ValueError("micro_clips must be positive")
+        self.keep_clips, self.micro_clips = keep_clips, micro_clips
+
+    def plan_split(self, n_clips: int, frames: int, micro_clips: int = 32, margin_bytes: int = 24 << 30) -> Tuple[int, int]:
+        """(keep_clips, micro_clips) for a local batch of `n_clips` x `frames` from the device memory that is free NOW: as many
+        clips kept as fit next to one micro-batch's activations and `margin_bytes` (backward scratch, the teacher's
+        workspace, losses); (n_clips, n_clips) - the plain step - when everything fits."""
+        lib, rt = _lib.load(), self.student._rt
+        per_clip = lib.fc_train_arena_bytes(rt.handle, 0, frames) + lib.fc_train_arena_bytes(rt.handle, 1, 1)
+        free, _ = torch.cuda.mem_get_info(self.student.params.device)
+        free += torch.cuda.memory_reserved(self.student.params.device) - torch.cuda.memory_allocated(self.student.params.device)
+        if (n_clips * per_clip + margin_bytes) <= free:
+            return n_clips, n_clips
+        micro = max(1, min(micro_clips, n_clips))
+        keep = int(max(0, free - margin_bytes - micro * per_clip) // per_clip)
+        keep = min(n_clips, keep // micro * micro)
+        return keep, micro
+
+    def _student_forward(self, video: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = video.shape[0]
+        keep = n if self.micro_clips is None else min(n, max(0, self.keep_clips or 0))
+        self._split = None
+        if keep >= n:
+            return self.student.forward(video, {"input_ids": ids})
+        if ids.shape[0] != n:
+            raise _lib.FitclipHipError("the split step pairs every clip with one caption (no `prompts` variant)")
+        sv_parts, st_parts, kept_state = [], [], None
+        if keep > 0:
+            v, t = self.student.forward(video[:keep], {"input_ids": ids[:keep]})
+            sv_parts.append(v), st_parts.append(t)
+            kept_state, self.student._state = self.student._state, None
+        with torch.no_grad():
+            for s0 in range(keep, n, self.micro_clips):
+                v, t = self.encoder(video=video[s0:s0 + self.micro_clips], text={"input_ids": ids[s0:s0 + self.micro_clips]})
+                sv_parts.append(v), st_parts.append(t)
+        self._split = {"keep": keep, "micro": self.micro_clips, "video": video, "ids": ids, "state": kept_state}
+        return torch.cat(sv_parts), torch.cat(st_parts)
 
     # -------------------------------------------------------------------------------------------- training_step_end
     def training_step_end(self, output: Mapping[str, Any]) -> float:
@@ -379,8 +434,21 @@ class TeacherStudentTrainer(TeacherStudentModule):
     def backward(self) -> None:
         if self._pending is None:
             raise _lib.FitclipHipError("backward() needs training_step_end() first")
-        self.student.backward(*self._pending)
+        d_video, d_text = self._pending
         self._pending = None
+        sp, self._split = self._split, None
+        if sp is None:
+            self.student.backward(d_video, d_text)
+            return
+        keep, micro, video, ids = sp["keep"], sp["micro"], sp["video"], sp["ids"]
+        n = video.shape[0]
+        if keep > 0:
+            self.student._state = sp["state"]
+            self.student.backward(d_video[:keep], d_text[:keep], accumulate=False, reduce_across_ranks=False)
+        for s0 in range(keep, n, micro):
+            e0 = min(n, s0 + micro)
+            self.student.forward(video[s0:e0], {"input_ids": ids[s0:e0]})
+            self.student.backward(d_video[s0:e0], d_text[s0:e0], accumulate=s0 > 0, reduce_across_ranks=e0 == n)
 
     # ----------------------------------------------------------------------------------------------- optimizer_step
     def optimizer_step(self) -> None:
@@ -419,12 +487,13 @@ class TeacherStudentTrainer(TeacherStudentModule):
         s = self.student
         state = {}
         step = torch.tensor(float(s.step_count))
+        shapes = dict(s.model._named_weights())
         for i, _, where in self._optimizer_slots():
             if isinstance(where, int):
                 state[i] = {"step": step.clone(), "exp_avg": self.scale_m[where:where + 1].cpu(),
                             "exp_avg_sq": self.scale_v[where:where + 1].cpu()}
             else:
-                o, shape = s.offsets[where], dict(s.model._named_weights())[where].shape
+                o, shape = s.offsets[where], shapes[where].shape
                 n = int(torch.Size(shape).numel())
                 state[i] = {"step": step.clone(), "exp_avg": s.exp_avg[o:o + n].view(shape).cpu(),
                             "exp_avg_sq": s.exp_avg_sq[o:o + n].view(shape).cpu()}

@@ -453,6 +453,42 @@ def test_micro_batched_forward_backward_accumulates(tiny_state_dict):
         assert _rel(b.grad, a.grad.cpu()) < 1e-5, k
 
 
+@pytest.mark.parametrize("keep,micro", [(4, 3), (0, 4), (6, 8), (10, 2)])
+def test_split_step_for_batches_larger_than_memory(tiny_state_dict, keep, micro):
+    """`TeacherStudentTrainer.split_step(keep, micro)` (BASELINE configs[4] on fewer than four GPUs: the activations of a rank's
+    share do not fit): the first `keep` clips keep their activations, the others are forwarded without and re-forwarded micro-batch
+    by micro-batch in the backward, gradients accumulated.  Embeddings are bit-invariant to their batch, so the LOSS and the
+    temperature gradients are bitwise those of the unsplit step; the parameter gradients differ by summation order only; with
+    everything kept (keep >= n) the step IS the unsplit one, bit for bit.  Two optimiser steps stay together."""
+    d = synth.TINY
+    student_np = synth.perturbed_state_dict(tiny_state_dict, d, seed=5, rel=0.3)
+    n, f, n_lab = 10, 2, 4
+    video = torch.from_numpy(synth.make_video(n, f, d, seed=11))
+    ids = torch.from_numpy(synth.make_text(n, d, seed=11))
+    whole, split = _trainer(student_np, tiny_state_dict, 0.05), _trainer(student_np, tiny_state_dict, 0.05)
+    split.split_step(keep, micro)
+    losses = []
+    for module in (whole, split):
+        losses.append(module.training_step_end(module.training_step(_batch(video, ids, n_lab))))
+        module.backward()
+    assert losses[0] == losses[1]
+    assert torch.equal(whole.scale_grads, split.scale_grads)
+    for (k, a), (_, b) in zip(whole.encoder.model.named_parameters(), split.encoder.model.named_parameters()):
+        if keep >= n:
+            assert torch.equal(a.grad, b.grad), k
+        else:
+            assert _rel(b.grad, a.grad.cpu()) < 1e-5, k
+    for module in (whole, split):
+        module.optimizer_step()
+    l2 = [module.fit_step(_batch(video, ids, n_lab)) for module in (whole, split)]
+    assert abs(l2[0] - l2[1]) < 1e-5 * abs(l2[0])
+    # (AdamW divides by sqrt(v): on elements whose gradient is rounding noise the two runs may step in opposite directions,
+    # one lr each and step)
+    assert float((whole.student.params - split.student.params).abs().max()) <= 4.001 * whole.student.lr
+    # the planner: everything fits on this device for a tiny model -> the plain step
+    assert split.plan_split(n, f) == (n, n)
+
+
 def test_train_command_reduces_the_distillation_loss(capsys):
     """`python -m fitclip_amd command=train encoder=teacher_student_tiny`: the distillation loop end to end (student
     forward / losses / backward / AdamW per step over synthetic mixed batches).  Repeating one batch (`repeat_batch`),
