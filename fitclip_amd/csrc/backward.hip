@@ -202,8 +202,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) quickgelu_kernel(const T* __restrict__ in, T* __restrict__ out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 v = ld4<T>(in + i * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f32(v[e]);  // slip.py:359-361; the same function as the GEMM epilogue
+    v = quick_gelu_f32x4(v);  // slip.py:359-361; the same function as the GEMM epilogue
     st4<T>(out + i * 4, v);
   }
 }

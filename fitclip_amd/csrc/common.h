@@ -265,13 +265,33 @@ __device__ __forceinline__ float sum_over_lane_groups(float x) {
 // instead of the 27 of expf + IEEE division.  The ONE definition used by the GEMM epilogues and the training kernels.
 __device__ __forceinline__ float sigmoid_1702(float x) {
   constexpr float kHi = -2.4554669857025146f, kLo = 2.6109498563187117e-08f;  // hi + lo = -1.702 * log2(e)
-  const float t = fminf(x * kHi, 126.f);                                     // 2^126: still finite, sigmoid ~ 1e-38
-  const float r = __builtin_fmaf(x, kHi, -(x * kHi)) + x * kLo;
-  float e = __builtin_amdgcn_exp2f(t);
+  const float p = x * kHi;
+  const float t = fminf(p, 126.f);                                           // 2^126: still finite, sigmoid ~ 1e-38
+  const float r = __builtin_fmaf(x, kLo, __builtin_fmaf(x, kHi, -p));        // (every fma spelled out: the pair form below
+  float e = __builtin_amdgcn_exp2f(t);                                       //  must perform the SAME operations)
   e = __builtin_fmaf(e, r * 0.6931471805599453f, e);
   return __builtin_amdgcn_rcpf(1.f + e);
 }
 __device__ __forceinline__ float quick_gelu_f32(float x) { return x * sigmoid_1702(x); }
+// The same function on a pair / on four values with the packed-fp32 instructions (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: two
+// elements per issue; only min, exp2 and rcp stay per element): 6.5 instead of 9.5 VALU instructions per element in the
+// epilogue of the c_fc GEMM, the same IEEE operations in the same order - bit-identical to quick_gelu_f32.
+__device__ __forceinline__ f32x2 quick_gelu_pair(const f32x2 x) {
+  constexpr float kHi = -2.4554669857025146f, kLo = 2.6109498563187117e-08f;
+  const f32x2 p = x * kHi;
+  const f32x2 t = {fminf(p[0], 126.f), fminf(p[1], 126.f)};
+  f32x2 r = __builtin_elementwise_fma(x, f32x2{kHi, kHi}, -p);
+  r = __builtin_elementwise_fma(x, f32x2{kLo, kLo}, r);
+  f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  e = __builtin_elementwise_fma(e, r * 0.6931471805599453f, e);
+  const f32x2 d = e + 1.f;
+  const f32x2 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return x * s;
+}
+__device__ __forceinline__ f32x4 quick_gelu_f32x4(const f32x4 x) {
+  const f32x2 lo = quick_gelu_pair(f32x2{x[0], x[1]}), hi = quick_gelu_pair(f32x2{x[2], x[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 // d/dx [x * sigmoid(1.702 x)] = s * (1 + 1.702 x (1 - s))
 __device__ __forceinline__ float quick_gelu_grad_f32(float x) {
   const float s = sigmoid_1702(x);

@@ -891,8 +891,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
               const int n = cn0 + wn * TN + j * 16 + 4 * q;
               f32x4 v = acc[i][j];
               if constexpr (EPI == EPI_GELU_T) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
+                v = quick_gelu_f32x4(v);  // (packed pairs; the bits of quick_gelu_exact)
               }
               if constexpr (EPI == EPI_DGELU_T) {
                 // (these loads make hipcc drain vmcnt before the stores; the counted wait of the next tile stays valid,

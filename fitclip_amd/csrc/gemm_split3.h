@@ -106,15 +106,19 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
     // activation rows: a 64-bit tile base + 32-bit offsets inside the tile (the x3 MLP rows of a pass may exceed 4 GiB)
     const int mb = ABL == 2 ? 0 : m0;
     a_tile = reinterpret_cast<const char*>(g.A) + (size_t)mb * lda_b;
+    // (the staging rows are rebuilt from an opaque copy of the lane id: what is only needed here, once per tile, must not stay in
+    // registers - or in scratch - across the K loop; the same in the epilogue below)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
 #pragma unroll
     for (int i = 0; i < LPA; ++i) {
-      const int c6 = (wave + i * NW) * 64 + lane, row = c6 / 6, c = c6 - row * 6;
+      const int c6 = (wave + i * NW) * 64 + lane_s, row = c6 / 6, c = c6 - row * 6;
       const int gr = min(row, g.M - 1 - mb);
       offA[i] = (unsigned)gr * lda_b + (unsigned)((c >> 1) * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4));
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
-      const int c6 = (wave + i * NW) * 64 + lane, row = c6 / 6, c = c6 - row * 6;
+      const int c6 = (wave + i * NW) * 64 + lane_s, row = c6 / 6, c = c6 - row * 6;
       const int gr = min((ABL == 2 ? 0 : n0) + row, g.N - 1);
       offB[i] = (unsigned)gr * ldw_b + (unsigned)((c >> 1) * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4));
     }
@@ -330,10 +334,13 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
       prev_counted = false;
     } else {
       char* stg = smem + s_aft + wave * PATCH;
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int r = lane_e & 31, h = lane_e >> 5;   // (epilogue-local copies)
       if constexpr (!kOutX3) {
         // f32 outputs: a 32 x 32 tile goes through the wave's 32-row x 128-byte patch (chunk ^ (row & 7): conflict-free
         // both ways) and leaves as 8 rows x 128 contiguous bytes per store instruction
-        const int rrow = lane >> 3, rch = lane & 7;
+        const int rrow = lane_e >> 3, rch = lane_e & 7;
         // EPI_RESID3_F32: every lane adds the 16 bytes of C it is about to overwrite (the residual stream, updated in place: the
         // LayerNorm behind the projection then reads ONE fp32 row and writes no row back).  They are requested RWIN tiles ahead
         // - whole lines per instruction and non-temporal, like the stores (the stream must not push the operand panels out of
@@ -385,10 +392,10 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
         // and leave as WHOLE 128-byte lines, 8 rows per store instruction (a line written only in part costs a
         // read-modify-write at the memory side).  The zero quarter of the patch is written once per tile.
         {
-          const int zrow = lane >> 1, zc = 6 + (lane & 1);
+          const int zrow = lane_e >> 1, zc = 6 + (lane_e & 1);
           *reinterpret_cast<f32x4*>(stg + zrow * 128 + ((zc ^ (zrow & 7)) << 4)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const int rrow = lane >> 3, rch = lane & 7;
+        const int rrow = lane_e >> 3, rch = lane_e & 7;
         const size_t ldc_b = (size_t)g.ldc * 2;
         char* cbase = reinterpret_cast<char*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * ldc_b + rch * 16;
         const int rd_off[4] = {(rrow) * 128 + ((rch ^ (rrow & 7)) << 4), (8 + rrow) * 128 + ((rch ^ (rrow & 7)) << 4),
@@ -405,8 +412,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
               for (int gh = 0; gh < 2; ++gh) {
                 const int gq = 2 * cg + gh;
                 f32x4 v = {acc[i][j][gq * 4], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_exact(v[e]);
+                v = quick_gelu_f32x4(v);  // (packed pairs; the bits of quick_gelu_exact)
                 bf16x4 p1, p2, p3;
                 split3(v, p1, p2, p3);
                 *reinterpret_cast<bf16x4*>(wr + (((0 + gh) ^ wx) << 4)) = p1;
