@@ -128,12 +128,19 @@ def audit_no_scratch(asm_path: Path, substrings) -> int:
     return checked
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
+LAB_LIB = REPO / "tools" / "bin" / "libfitclip_hip_lab.so"
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True, lab: bool = False) -> Path:
+    """`lab=True` builds tools/bin/libfitclip_hip_lab.so with -DFITCLIP_LAB: the same sources plus the A/B switches the lab
+    scripts under tools/ read from the environment (select it with FITCLIP_HIP_LIB=...).  The product library never defines it."""
     hipcc = _hipcc()
-    objdir = CSRC / "build"
+    objdir = CSRC / ("build_lab" if lab else "build")
     objdir.mkdir(exist_ok=True)
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-             "-fvisibility=hidden", "-DFITCLIP_BUILD"]
+             "-fvisibility=hidden", "-DFITCLIP_BUILD"] + (["-DFITCLIP_LAB"] if lab else [])
+    lib_path = LAB_LIB if lab else LIB
+    lib_path.parent.mkdir(exist_ok=True)
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src.replace(".hip", ".o").replace(".cpp", ".o"))
@@ -159,14 +166,13 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-lz"]
+    if force or _stale(lib_path, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib_path), *map(str, objs), "-lz"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, lab="--lab" in sys.argv))

@@ -310,10 +310,6 @@ int gemm_x3(fc_handle* h, int epi, const void* A3, const void* W3, const float* 
   GemmArgs a{};
   a.A = A3; a.W = W3; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
   a.M = M; a.N = N; a.K = K; a.lda = (int)x3_row_elems(K); a.ldw = a.lda; a.ldc = ldc; a.P = 0;
-  // c_fc (12 column tiles): four XCD groups split the N range, so that only a quarter of the 19 MB x3 weight cycles through
-  // each 4 MiB L2 (lab, 512 frames: 7.4 -> 3.6 GB fetched per launch, 2.43 -> 2.31 ms; the shapes with 3 or 9 column tiles
-  // cannot be split over 2, 4 or 8 groups)
-  if ((N / 256) % 4 == 0 && N / 256 >= 8 && N % 256 == 0) a.nsplit = 4;
   GemmArgs rec = a;  // the profiling record counts the bf16 work: six products per fp32 product
   rec.K = 6 * K;
   ProfScope ps(h, st, PREC_BF16, epi, 3, rec);

@@ -45,7 +45,9 @@ constexpr int prod_w(int x) { return x == 1 || x == 3 ? 1 : (x == 4 ? 2 : 0); }
 // SPREAD: 0 = the six LDS-DMA pieces a wave contributes to K-step k + 3 are issued in one burst at the hand-over of step k;
 // 1 = they are issued during step k + 1, two behind each of its first three MFMA groups (the stage is free since the
 // hand-over of step k; they still have more than a K-step to land).
-template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4>
+// NTA (lab): cache policy of the ACTIVATION LDS-DMA pieces (2 = nt: a stream that is read once per XCD should not push the
+// weight tiles out of L2); RR (lab): tiles dealt round robin in N-fastest order instead of the XCD panel ranges.
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int NTA = 0, int RR = 0>
 __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 x 64 per wave
@@ -81,8 +83,10 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   const int mp0 = xi < pr ? xi * (pq + 1) : pr * (pq + 1) + (xi - pr) * pq;
   const int npanel = pq + (xi < pr ? 1 : 0);
   const int tnn = tilesN / ngrp, tn0 = grp * tnn;
-  const int t_end = npanel * tnn;
-  int t = pos;
+  const int qd_ = G >> 3, rd_ = G & 7;
+  const int wk = (xcd < rd_ ? xcd * (qd_ + 1) : rd_ * (qd_ + 1) + (xcd - rd_) * qd_) + pos;   // XCD-major workgroup number
+  const int t_end = RR ? tilesM * tilesN : npanel * tnn;
+  int t = RR ? wk : pos;
   if (t >= t_end) return;
 
   const int nk = g.K / X3_GROUP;                   // K-steps: one 128-byte line of every operand row each (even, >= 4)
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
   const char* a_tile = reinterpret_cast<const char*>(g.A);  // 64-bit base of the current tile's first activation row (scalar)
   // piece i of this wave covers chunks (wave + 8 i) * 64 + lane of the [rows][6 chunks] image of its operand tile
   auto tile_sources = [&](int tile, int& m0, int& n0) {
-    const int tm = mp0 + tile / tnn, tn = tn0 + tile % tnn;
+    const int tm = RR ? tile / tilesN : mp0 + tile / tnn, tn = RR ? tile % tilesN : tn0 + tile % tnn;
     m0 = tm * BM;
     n0 = tn * BN;
     // neighbouring column tiles run ONE K-step apart: a line fetched for one column tile is still in L2 when the next tile
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
     for (int i = 0; i < LPA; ++i)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * X3_GROUP_BYTES)),
-          (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, NTA);
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
       __builtin_amdgcn_global_load_lds(
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
     if constexpr (idx < LPA)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * X3_GROUP_BYTES)),
-          (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, NTA);
     else
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[idx - LPA] + (unsigned)kt * X3_GROUP_BYTES)),
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(512) gemm_split3_kernel(const GemmArgs g) {
       }
     }
     const int cm0 = m0, cn0 = n0;
-    const int tnext = t + nblk;
+    const int tnext = t + (RR ? G : nblk);
     const bool has_next = tnext < t_end;
 
     // one K-step; PAR = kt & 1 = fragment-register set of this step (nk is even, so a tile starts at parity 0)

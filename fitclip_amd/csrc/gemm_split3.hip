@@ -2,24 +2,45 @@
 #include "gemm_split3.h"
 
 #include <algorithm>
+#ifdef FITCLIP_LAB
+#include <cstdlib>
+#endif
 
 namespace fc {
 
 namespace {
 
-template <int EPI, int RW = 4>
-int launch_one(const GemmArgs& a, hipStream_t stream) {
+template <int EPI, int RW = 4, int NTA = 0, int RR = 0>
+int launch_variant(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = 3 * 512 * 96 + 2048;  // three stages (the epilogue borrows the released one) + two bias slices
   // SPREAD = 1: the LDS-DMA pieces of a K-step are issued two at a time behind MFMA groups of the step before (lab: 4 - 8 % over
   // one burst of six per wave at the hand-over - with the bursts the L1's pending-miss queue fills, the TA stalls, and a wave
   // stuck on a DMA instruction issues no MFMAs: TCP_PENDING_STALL_CYCLES 24 % of the launch, tools/split3_lab + rocprofv3)
-  auto kern = gemm_split3_kernel<EPI, 0, 1, RW>;
+  auto kern = gemm_split3_kernel<EPI, 0, 1, RW, NTA, RR>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split3: cannot raise dynamic LDS to %d bytes", lds);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), lds, stream, a);
   FC_CHECK_LAUNCH("gemm_split3");
   return FC_OK;
+}
+
+template <int EPI, int RW = 4>
+int launch_one(const GemmArgs& a, hipStream_t stream) {
+#ifdef FITCLIP_LAB  // (tools/ only: libfitclip_hip_lab.so; the product library has no environment-dependent behaviour)
+  static const int lab = [] { const char* e = getenv("FITCLIP_LAB_SPLIT3"); return e ? atoi(e) : 0; }();
+  GemmArgs b = a;
+  if (lab & 4) b.nsplit = 1;
+  if (lab & 8) b.nsplit = 2;
+  switch (lab & 3) {
+    case 1: return launch_variant<EPI, RW, 2, 0>(b, stream);   // nt activations
+    case 2: return launch_variant<EPI, RW, 0, 1>(b, stream);   // round-robin deal
+    case 3: return launch_variant<EPI, RW, 2, 1>(b, stream);
+    default: return launch_variant<EPI, RW, 0, 0>(b, stream);
+  }
+#else
+  return launch_variant<EPI, RW, 0, 0>(a, stream);
+#endif
 }
 
 // fp32 rows -> x3 rows: thread per (row, line of 16 columns, half): 8 values -> three 16-byte chunks (+ 16 zero bytes of the
@@ -70,19 +91,24 @@ int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream) {
   if (!a.bias || ((uintptr_t)a.bias & 15)) return fail(FC_EINVAL, "gemm_split3: bias missing or unaligned");
   if ((size_t)256 * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32))
     return fail(FC_EINVAL, "gemm_split3: the weight (or a 256-row tile of the activations) exceeds the 4 GiB of the kernel's 32-bit row offsets");
+  GemmArgs b = a;
+  // c_fc (12 column tiles): four XCD groups split the N range, so that only a quarter of the 19 MB x3 weight cycles through
+  // each 4 MiB L2 (lab, 512 frames: 7.4 -> 3.6 GB fetched per launch, 2.43 -> 2.31 ms; the shapes with 3 or 9 column tiles
+  // cannot be split over 2, 4 or 8 groups)
+  if (b.nsplit == 0 && (b.N / 256) % 4 == 0 && b.N / 256 >= 8 && b.N % 256 == 0) b.nsplit = 4;
   switch (epilogue) {
     case EPI_BIAS_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split3: ldc=%d", a.ldc);
-      return launch_one<EPI_BIAS_F32>(a, stream);
+      return launch_one<EPI_BIAS_F32>(b, stream);
     case EPI_RESID3_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split3: ldc=%d", a.ldc);
       // two tiles of the stream in flight: windows of 2, 3 and 4 measure the same (709 / 708 / 707 pairs/s on the bench step),
       // and the wider ones spill - the first fragments of the next tile are live across the epilogue
-      return launch_one<EPI_RESID3_F32, 2>(a, stream);
+      return launch_one<EPI_RESID3_F32, 2>(b, stream);
     case EPI_GELU_X3:
       if (a.ldc % 64 || a.ldc < x3_row_elems(a.N) || ((uintptr_t)a.C & 127))
         return fail(FC_EINVAL, "gemm_split3: the x3 output needs 128-byte aligned rows of >= 4 N bf16 (ldc=%d)", a.ldc);
-      return launch_one<EPI_GELU_X3>(a, stream);
+      return launch_one<EPI_GELU_X3>(b, stream);
   }
   return fail(FC_EINVAL, "gemm_split3: epilogue %d", epilogue);
 }
