@@ -428,6 +428,11 @@ __global__ void __launch_bounds__(256) seq_sum_kernel(const float* __restrict__ 
 //     segment's start, and `perm[start[id] + rank[row]] = row` lists each segment in ascending row order.
 // (2) `token_segment_sum_kernel`: one wave per (row, 64-column slice); only the FIRST row of an id works: it walks its
 //     id's segment of `perm` and adds the rows in that order (eight loads in flight, adds strictly sequential).
+//     BOUND: the longest segment is a serial chain.  The pad id holds (77 - mean caption length) rows of every caption - about
+//     60 % of all rows - so one wave per 64-column slice walks ~24 k of the 39 k rows of a 512-caption batch: ~3 ms (the step is
+//     ~4 s there, ~50 us at 64 captions); it grows linearly with the captions of ONE rank, not with the global batch.  A fixed
+//     tree (sub-blocks summed by separate waves, partials combined in index order) would keep the result reproducible but
+//     change the bits away from numpy's sequential `np.add.at`, which the tests pin; not done while the cost is < 0.1 %.
 __global__ void __launch_bounds__(1024) token_order_kernel(const int64_t* __restrict__ ids, int rows, int vocab,
                                                            int* __restrict__ cnt, int* __restrict__ start,
                                                            int* __restrict__ rank, int* __restrict__ perm) {

@@ -11,7 +11,7 @@ padding / duplication of its DDP sampler (the shards here are exact).
 from __future__ import annotations
 
 import os
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -105,18 +105,24 @@ def metrics_from_ranks(ranks: np.ndarray) -> Dict[str, float]:
 
 
 def sharded_retrieval(local_videos: torch.Tensor, local_texts: torch.Tensor, n_total: int,
-                      similarity: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
-                      ranks_of: Callable[[torch.Tensor, int], torch.Tensor]) -> Dict[str, float]:
+                      similarity: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None,
+                      ranks_of: Optional[Callable[[torch.Tensor, int], torch.Tensor]] = None,
+                      similarity_ranks: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None
+                      ) -> Dict[str, float]:
     """Epoch-end scoring (text_video_retrieval.py:67-83) over embeddings sharded by clip.
 
-    `similarity(T_local, V_all)` -> [n_local, n_total] scores; `ranks_of(scores, offset)` -> rank of column
-    `offset + i` in row i.  Both are the HIP operators in production; the CPU tests inject the oracle's.
+    `similarity_ranks(T_local, V_all, offset)` -> rank of column `offset + i` in row i of T_local @ V_all^T, computed WITHOUT the
+    [n_local, n_total] score matrix (production: `ops.similarity_ranks`, the comparison runs in the scoring GEMM's epilogue);
+    or the two-step form `similarity(T_local, V_all)` -> scores, `ranks_of(scores, offset)` -> ranks (the CPU tests inject the
+    oracle's functions there).
     """
     rank, world_size = world()
     counts = shard_counts(n_total, world_size)
     start, _ = shard_bounds(n_total, world_size, rank)
     all_videos = all_gather_rows(local_videos, counts)
-    scores = similarity(local_texts, all_videos)
-    local_ranks = ranks_of(scores, start).to(torch.int32)
+    if similarity_ranks is not None:
+        local_ranks = similarity_ranks(local_texts, all_videos, start).to(torch.int32)
+    else:
+        local_ranks = ranks_of(similarity(local_texts, all_videos), start).to(torch.int32)
     all_ranks = all_gather_rows(local_ranks, counts)
     return metrics_from_ranks(all_ranks.cpu().numpy())

@@ -80,13 +80,14 @@ class TextVideoRetrievalModule(VideoTextModule):
 
     def validation_epoch_end(self) -> Dict[str, float]:
         """cat all batches, scores = T @ V^T, target = arange, R@1/5/10 + median rank
-        (text_video_retrieval.py:67-83)."""
+        (text_video_retrieval.py:67-83); the scores only ever exist tile by tile inside `fc_similarity_ranks`."""
         encoded_videos = torch.cat([o[0] for o in self._outputs])
         encoded_texts = torch.cat([o[1] for o in self._outputs])
         rank, world_size = D.world()
         n_total = self.n_total if self.n_total is not None else len(encoded_videos) * world_size
-        metrics = D.sharded_retrieval(encoded_videos, encoded_texts, n_total, ops.similarity,
-                                      lambda s, off: ops.ranks(s, off))
+        # (ranks straight from the scoring GEMM's epilogue: no [n_local, n_total] score matrix - 268 MB at 8192 x 8192)
+        metrics = D.sharded_retrieval(encoded_videos.contiguous(), encoded_texts.contiguous(), n_total,
+                                      similarity_ranks=lambda t, v, off: ops.similarity_ranks(t, v, off))
         losses = torch.stack([torch.as_tensor(l, device=encoded_videos.device).reshape(()) for l, _ in self._losses]).double()
         sizes = torch.tensor([float(b) for _, b in self._losses], dtype=torch.float64, device=encoded_videos.device)
         num = torch.stack([(losses * sizes).sum(), sizes.sum()])

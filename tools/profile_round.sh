@@ -1,14 +1,15 @@
 #!/bin/bash
 # Reproduces the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun, from the repo root):
-#   tools/profile_round.sh r03 fp32        # the headline precision
-#   tools/profile_round.sh r03 bf16        # the secondary mode
-#   tools/profile_round.sh r03 fp32x6      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on)
+#   tools/profile_round.sh r04 fp32        # the headline precision
+#   tools/profile_round.sh r04 bf16        # the secondary mode
+#   tools/profile_round.sh r04 fp32x6      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on)
+#   tools/profile_round.sh r04 c3          # bench.py --config c3 (encoder=wise, eval batches of 32 clips = 128 frames per call)
 # 1. kernel trace + stats of the bench command for that precision (CPU leg and the other precision off);
 # 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) and 4. an SQ pass for the dominant kernel (c_fc + QuickGELU GEMM).
 # Raw output goes to gpurun_out/prof_*; summaries to profiles/ AND gpurun_out/profiles_<tag>/ (the latter travels back).
 # The program stays directly after `--` (no env / bash -c hop: the profiler has already initialised the GPU).
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 prec=${2:-fp32}
 repo=$(pwd)
 out=$repo/gpurun_out
@@ -25,7 +26,15 @@ export FITCLIP_OVERLAP_TEXT=0
 # (fp32 and bf16: the 2048 frames of a bench step run as ONE pass)
 # c_fc (+QuickGELU) has its own instantiation; c_proj shares one with out_proj (the residual epilogue, 2) and is told apart by
 # its duration window (fp32 @ 2048 frames: c_proj 13.2 ms, out_proj 3.5; bf16 @ 2048: 1.8 / 0.55)
-if [ "$prec" = fp32 ]; then
+bench_args=""
+if [ "$prec" = c3 ]; then
+  # the reference-shaped call: 128 frames per encoder call (M = 25 216).  c_proj and out_proj share one instantiation (residual
+  # epilogue, tail of 64-row tiles: HT = 1) and are told apart by duration (c_proj 0.93 ms, out_proj 0.26 ms); c_fc (QuickGELU)
+  # has its own (0.87 ms; the text tower's c_fc runs on the 64 x 64 ring kernel, another name)
+  steps=1; chunk=128; rows=$((chunk * 197)); bench_args="--config c3"
+  spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|600|2000|$rows|3072|768|bias_quickgelu"
+  spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 2,|700|2000|$rows|768|3072|bias_residual"
+elif [ "$prec" = fp32 ]; then
   steps=3; chunk=2048; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernel<float, 256, 256, 2, 4, 1,|9000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernel<float, 256, 256, 2, 4, 2,|9800|1e9|$rows|768|3072|bias_residual"
@@ -42,31 +51,33 @@ else
   spec_fc="gemm_split3_kernel<7,|3000|1e9|$rows|3072|4608|bias_quickgelu_x3_out"
   spec_proj="gemm_split3_kernel<8,|2900|1e9|$rows|768|18432|bias_residual_f32_out"
 fi
-if [ "$prec" = fp32x6 ]; then
+if [ "$prec" = c3 ]; then
+  common="--config c3 --no-cpu-baseline --headline-only"
+elif [ "$prec" = fp32x6 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
 else
   common="--precision $prec --no-bf16-mode --no-split-mode --no-cpu-baseline --no-train-leg"
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup 2 $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup $([ "$prec" = c3 ] && echo 1 || echo 2) $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
 echo "trace pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_fetch_$prec.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_fetch_$prec.err"
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/prof_write_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_write_$prec.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/prof_write_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_write_$prec.err"
 echo "write pass done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/prof_sq_$prec" -o bench -- python3 "$repo/bench.py" --steps 2 --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_sq_$prec.err" || echo "SQ pass failed (counters may need separate passes)"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/prof_sq_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_sq_$prec.err" || echo "SQ pass failed (counters may need separate passes)"
 echo "sq pass done"
 cd "$repo"
 find "$out/prof_trace_$prec" -name "*kernel_stats.csv" -exec cp {} "$keep/${tag}_bench_${prec}_kernel_stats.csv" \;
 trace=$(find "$out/prof_trace_$prec" -name "*kernel_trace.csv" | head -1)
 if [ "$prec" != fp32x6 ]; then  # (the split leg shares its trace with the fp32 leg: only the kernel table is kept)
-  python3 tools/trace_summary.py "$trace" $chunk $prec > "$keep/${tag}_bench_${prec}_trace_summary.txt"
+  python3 tools/trace_summary.py "$trace" $chunk $([ "$prec" = c3 ] && echo fp32 || echo $prec) > "$keep/${tag}_bench_${prec}_trace_summary.txt"
 fi
 cp "$out/prof_trace_$prec.json" "$keep/${tag}_bench_${prec}_under_rocprof.json"
 f=$(find "$out/prof_fetch_$prec" -name "*counter_collection.csv" | head -1)
 w=$(find "$out/prof_write_$prec" -name "*counter_collection.csv" | head -1)
 q=$(find "$out/prof_sq_$prec" -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py --fetch "$f" --write "$w" ${q:+--sq "$q"} --spec "$spec_fc" --spec "$spec_proj" \
-  --precision $prec --out "$keep/traffic_${tag}_${prec}.json"
+  --precision $([ "$prec" = c3 ] && echo fp32 || echo $prec) --out "$keep/traffic_${tag}_$([ "$prec" = c3 ] && echo fp32_c3 || echo $prec).json"
 cp "$keep"/* profiles/
 # the raw traces are large: keep only the summaries for the trip back
 rm -rf "$out/prof_trace_$prec" "$out/prof_fetch_$prec" "$out/prof_write_$prec" "$out/prof_sq_$prec"
