@@ -25,6 +25,7 @@ ARCH = "gfx950"
 NO_SCRATCH_AUDIT = {
     "gemm.hip": ["gemm_pipelined_kernel", "gemm_kernel"],
     "gemm_split3.hip": ["gemm_split3_kernel"],
+    "attention_split.hip": ["attn_split_kernel"],
     "attention.hip": ["attn_f32_blocks_kernel", "attn_f32_mfma_kernel", "attn_bf16_v2_kernel"],
     "rowops.hip": ["layernorm_kernel", "layernorm_pair_kernel"],
 }

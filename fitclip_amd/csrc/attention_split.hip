@@ -107,9 +107,13 @@ struct Ctx {
   template <int N>
   __device__ __forceinline__ void load_kv(const float* base, int isv, f32x4 (&raw)[N][2]) const {
     if (stage0 < 0) return;
+    // (staging addresses are rebuilt from an opaque copy of the lane id at every call: hipcc would otherwise hoist them out of
+    // the persistent loop over the (image, head) items and keep them - spilled - across the products)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
 #pragma unroll
     for (int it = 0; it < N; ++it) {
-      const int item = stage0 + it * 64 + lane, key = item >> 3, c = item & 7;
+      const int item = stage0 + it * 64 + lane_s, key = item >> 3, c = item & 7;
       const float* src = base + (isv ? 2 * D : D) + (long)min(key, S - 1) * ld + c * 8;
       raw[it][0] = *reinterpret_cast<const f32x4*>(src);
       raw[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
@@ -119,9 +123,11 @@ struct Ctx {
   template <int N>
   __device__ __forceinline__ void store_kv(int isv, const f32x4 (&raw)[N][2]) const {
     if (stage0 < 0) return;
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
 #pragma unroll
     for (int it = 0; it < N; ++it) {
-      const int item = stage0 + it * 64 + lane, key = item >> 3, c = item & 7;
+      const int item = stage0 + it * 64 + lane_s, key = item >> 3, c = item & 7;
       if (item < NKR * 8) {
         bf16x8 p1, p2, p3;
         split3x8(raw[it][0], raw[it][1], p1, p2, p3);

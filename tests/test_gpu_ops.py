@@ -213,6 +213,27 @@ def test_similarity_ranks_equal_the_materialised_path(nt, nv, dim, offset):
     assert ops.similarity_ranks(ti.to(DEV), vi.to(DEV), offset).tolist() == want.tolist()
 
 
+def test_new_gemm_paths_at_the_edges():
+    """Ragged and tiny problems through every fp32 kernel of the block epilogues: fewer rows than one 64-row unit, rows that end
+    inside a unit, one column tile, K at the pipelined kernel's minimum (3 K-tiles) - forced row cuts (tiles 4..7), the 64 x 64
+    ring (8) and the planned cut (3) against the plain 128 x 128 kernel, bitwise; and the scoring epilogue on empty / one-row /
+    one-column inputs."""
+    for M, N, K in ((1, 256, 96), (63, 256, 96), (65, 512, 128), (257, 264, 96), (700, 768, 2048)):
+        a, w, bias = _rand(M, K, seed=M).to(DEV), _rand(N, K, seed=N, scale=K ** -0.5).to(DEV), _rand(N, seed=3).to(DEV)
+        resid = _rand(M, N, seed=4).to(DEV)
+        for epi in (ops.EPI_BIAS_T, ops.EPI_GELU_T, ops.EPI_RESID_F32):
+            def run(tile):
+                return ops.gemm(a, w, bias, epi, out=resid.clone() if epi == ops.EPI_RESID_F32 else None, tile=tile)
+            want = run(1)
+            for tile in (3, 4, 5, 6, 7, 8, 2):
+                assert torch.equal(run(tile), want), (M, N, K, epi, tile)
+    t, v = _rand(5, 64, seed=1).to(DEV), _rand(9, 64, seed=2).to(DEV)
+    assert ops.similarity_ranks(t[:0], v).shape == (0,)
+    assert ops.similarity_ranks(t[:1], v[:1]).tolist() == [0]
+    assert ops.similarity_ranks(t, v[:1]).tolist() == [0] * 5                      # one column: every target is clamped onto it
+    assert ops.similarity_ranks(t, v, 7).tolist() == ops.ranks(ops.similarity(t, v), 7).tolist()   # offsets past the last column
+
+
 def test_loss_matches_reference_fixture(golden_dir):
     g = np.load(golden_dir / "loss_ref.npz")
     for t in sorted({k.rsplit("_", 1)[0] for k in g.files}):

@@ -51,8 +51,12 @@ else
   spec_fc="gemm_split3_kernel<7,|3000|1e9|$rows|3072|4608|bias_quickgelu_x3_out"
   spec_proj="gemm_split3_kernel<8,|2900|1e9|$rows|768|18432|bias_residual_f32_out"
 fi
+pmc_extra=""
 if [ "$prec" = c3 ]; then
   common="--config c3 --no-cpu-baseline --headline-only"
+  # (PMC passes serialise every dispatch: an epoch of 128 batches x ~330 launches takes many minutes under --pmc and has crashed
+  # the profiler; 8 batches of 32 clips run the same kernels on the same shapes)
+  pmc_extra="--total-clips 256"
 elif [ "$prec" = fp32x6 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
 else
@@ -60,11 +64,11 @@ else
 fi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_trace_$prec" -o bench -- python3 "$repo/bench.py" --steps $steps --warmup $([ "$prec" = c3 ] && echo 1 || echo 2) $common > "$out/prof_trace_$prec.json" 2> "$out/prof_trace_$prec.err"
 echo "trace pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_fetch_$prec.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/prof_fetch_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common $pmc_extra > /dev/null 2> "$out/prof_fetch_$prec.err"
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/prof_write_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_write_$prec.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/prof_write_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common $pmc_extra > /dev/null 2> "$out/prof_write_$prec.err"
 echo "write pass done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/prof_sq_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common > /dev/null 2> "$out/prof_sq_$prec.err" || echo "SQ pass failed (counters may need separate passes)"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/prof_sq_$prec" -o bench -- python3 "$repo/bench.py" --steps $([ "$prec" = c3 ] && echo 1 || echo 2) --warmup 1 --no-plant $common $pmc_extra > /dev/null 2> "$out/prof_sq_$prec.err" || echo "SQ pass failed (counters may need separate passes)"
 echo "sq pass done"
 cd "$repo"
 find "$out/prof_trace_$prec" -name "*kernel_stats.csv" -exec cp {} "$keep/${tag}_bench_${prec}_kernel_stats.csv" \;

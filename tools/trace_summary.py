@@ -86,9 +86,12 @@ def main():
             item[0] = "text " + item[0]
     # a step may run passes of different sizes (fp32: whole tile rounds first, the rest after): launches well below the
     # label's longest belong to the short pass and are listed apart, so that the TF/s of the main pass are not diluted
-    longest = defaultdict(float)
+    # (the reference level of a label is its 90th-percentile duration, not its maximum: the first launch of a process can run
+    # twice as long as the others)
+    by_label = defaultdict(list)
     for label, dur in labelled:
-        longest[label] = max(longest[label], dur)
+        by_label[label].append(dur)
+    longest = defaultdict(float, {k: sorted(v)[int(0.9 * (len(v) - 1))] for k, v in by_label.items()})
     agg = defaultdict(list)
     for label, dur in labelled:
         if label in shapes and dur < 0.6 * longest[label]:
