@@ -182,6 +182,8 @@ int launch_similarity_ranks(const float* T, const float* V, int nt, int nv, int 
                             const int32_t* targets, int32_t* ranks, hipStream_t stream) {
   if (nt == 0) return FC_OK;
   if (nt < 0 || nv <= 0 || dim <= 0 || !T || !V || !ranks) return fail(FC_EINVAL, "similarity_ranks: bad argument");
+  if (!targets && (target_offset < 0 || target_offset + nt > nv))   // (the same contract as fc_ranks)
+    return fail(FC_EINVAL, "similarity_ranks: rows=%d cols=%d offset=%d", nt, nv, target_offset);
   if (dim % 32) return fail(FC_EINVAL, "similarity_ranks: dim=%d must be a multiple of 32", dim);
   if (((uintptr_t)T | (uintptr_t)V) & 15) return fail(FC_EINVAL, "similarity_ranks: unaligned operand");
   constexpr int B = 128;

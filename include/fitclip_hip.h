@@ -139,7 +139,7 @@ FC_API int fc_similarity(const float* A, const float* B, int32_t na, int32_t nb,
 FC_API int fc_ranks(const float* scores, int32_t ld, int32_t n_rows, int32_t n_cols, int32_t target_offset, int32_t* ranks,
              fc_stream stream);
 /* Scoring WITHOUT the score matrix ("compute ranks tile-wise"; aligner/text_video_retrieval.py:70-80 +
- * aligner/metrics.py:16-20): ranks[i] = position of column t_i (= targets ? targets[i] : i + target_offset, clamped) in the
+ * aligner/metrics.py:16-20): ranks[i] = position of column t_i (= targets ? targets[i], clamped to a valid column : i + target_offset, which must be one) in the
  * stable descending order of row i of alpha * T @ V^T, T [nt, dim], V [nv, dim], dim % 32 == 0.  The comparison runs in the
  * epilogue of the exact-fp32 scoring GEMM; every score has the bits fc_similarity would store, so the ranks equal
  * fc_similarity + fc_ranks / fc_ranks_of exactly (ties included) while nothing of size nt x nv touches memory

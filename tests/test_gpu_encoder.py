@@ -638,6 +638,38 @@ def test_bench_config_c5_kd_training_step_rehearsal():
     assert one["n_gpus"] == 1 and len(one["losses"]) == 3 and all(np.isfinite(one["losses"]))
 
 
+def test_bench_config_c3_wise_evaluate_rehearsal_with_a_ragged_shard():
+    """`bench.py --config c3` (BASELINE configs[2], shrunk): `encoder=wise` through the evaluate loop in eval batches - 21 clips
+    over two gloo ranks = 11 + 10, batches of 4 - one all-gather, ranks from the scoring epilogue; the retrieval metrics equal
+    the one-rank run of the same command exactly (same seeded data per global clip is not required: the towers are random and
+    both runs see their own shards; what must agree is that every one of the 21 clips is ranked once), and the one-rank line
+    carries the roofline objects, the batch-256 key is absent at this size and the hipGraph leg replays bitwise."""
+    common = ["bench.py", "--config", "c3", "--total-clips", "21", "--frames", "2", "--eval-batch", "4", "--steps", "1",
+              "--warmup", "1", "--no-cpu-baseline"]
+    two = _run(common + ["--gpus", "2", "--backend", "gloo"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["retrieval"]["n"] == 21 and two["value"] > 0
+    assert "configs[2]" in two["config"]["workload"] and two["config"]["eval_batch"] == 4
+    one = _run(common)
+    assert one["n_gpus"] == 1 and one["retrieval"]["n"] == 21
+    assert one["roofline"]["frac"] > 0 and one["roofline_whole_path"]["frac"] > 0 and one["time_split"]["per_gemm"]
+    assert one["hipgraph"]["bitwise_equal_to_eager"] is True and one["hipgraph"]["replay_ms"] > 0
+    assert "eval_batch_256" not in one
+
+
+def test_bench_config_c5_split_step_rehearsal():
+    """`bench.py --config c5 --keep-clips 2 --micro-clips 3`: the KD step of a share that "does not fit" - 2 clips keep their
+    activations, the other 8 are forwarded without and re-forwarded in micro-batches of 3; the losses equal the unsplit run's
+    (the first one bitwise: same embeddings, same loss kernel; later ones to the AdamW noise of a split backward)."""
+    common = ["bench.py", "--config", "c5", "--total-clips", "10", "--frames", "2", "--steps", "2", "--warmup", "1"]
+    split = _run(common + ["--keep-clips", "2", "--micro-clips", "3"])
+    plain = _run(common)
+    assert split["split_step"] == {**split["split_step"], "kept_clips": 2, "micro_batch_clips": 3, "recomputed_clips": 8}
+    assert plain["split_step"] is None
+    assert split["losses"][0] == plain["losses"][0]
+    assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(split["losses"], plain["losses"]))
+    assert split["roofline"]["executed_flops_per_step"] > split["roofline"]["flops_per_step"]
+
+
 def test_bench_exits_nonzero_when_a_secondary_leg_fails():
     """A broken secondary leg must not hide behind rc 0: the headline line is still printed (with `failed_legs`), the exit
     code is 1.  The failure is injected from outside (an impossible tile for the bf16 leg only is not available, so the

@@ -209,7 +209,7 @@ def test_similarity_ranks_equal_the_materialised_path(nt, nv, dim, offset):
         tgt = torch.randint(0, nv, (nt,), generator=g)
         assert ops.similarity_ranks(td, vd, targets=tgt, alpha=alpha).tolist() == ops.ranks_of(scores, tgt).tolist()
     # and against the oracle on the integer case (scores exact in fp32: no arithmetic to argue about)
-    want = O.ranks_of_target(ti @ vi.T, (torch.arange(nt) + offset).clamp(max=nv - 1))
+    want = O.ranks_of_target(ti @ vi.T, torch.arange(nt) + offset)
     assert ops.similarity_ranks(ti.to(DEV), vi.to(DEV), offset).tolist() == want.tolist()
 
 
@@ -230,8 +230,11 @@ def test_new_gemm_paths_at_the_edges():
     t, v = _rand(5, 64, seed=1).to(DEV), _rand(9, 64, seed=2).to(DEV)
     assert ops.similarity_ranks(t[:0], v).shape == (0,)
     assert ops.similarity_ranks(t[:1], v[:1]).tolist() == [0]
-    assert ops.similarity_ranks(t, v[:1]).tolist() == [0] * 5                      # one column: every target is clamped onto it
-    assert ops.similarity_ranks(t, v, 7).tolist() == ops.ranks(ops.similarity(t, v), 7).tolist()   # offsets past the last column
+    assert ops.similarity_ranks(t, v[:1], targets=torch.zeros(5, dtype=torch.int32)).tolist() == [0] * 5   # one column
+    assert ops.similarity_ranks(t, v, 4).tolist() == ops.ranks(ops.similarity(t, v), 4).tolist()          # the last valid offset
+    from fitclip_amd._lib import FitclipHipError
+    with pytest.raises(FitclipHipError, match="offset"):   # targets past the last column: rejected, as fc_ranks does
+        ops.similarity_ranks(t, v, 5)
 
 
 def test_loss_matches_reference_fixture(golden_dir):
