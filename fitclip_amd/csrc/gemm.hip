@@ -2,6 +2,9 @@
 #include "gemm_kernel.h"
 
 #include <algorithm>
+#ifdef FITCLIP_LAB
+#include <cstdlib>
+#endif
 
 namespace fc {
 
@@ -90,6 +93,10 @@ int launch_pipelined(const GemmArgs& a, int forced_ht, hipStream_t stream) {
     if (forced_ht > 0) p = TailPlan{(int)std::min<long>(panels - 1, (long)panels * tilesN / cus * cus / tilesN), forced_ht};
     GemmArgs b = a;
     b.hp = p.hp;
+#ifdef FITCLIP_LAB
+    static const int lab_order = [] { const char* e = getenv("FITCLIP_LAB_GEMM_ORDER"); return e ? atoi(e) : 0; }();
+    b.order = lab_order;
+#endif
     switch (p.ht) {
       case 1: return launch_pipelined_ht<T, EPI, SCHED, 1>(b, stream);
       case 2: return launch_pipelined_ht<T, EPI, SCHED, 2>(b, stream);

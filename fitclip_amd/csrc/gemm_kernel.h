@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // and every workgroup gets the same number of tiles to within one.  (The panel-range partition above quantises PER XCD: 85
   // panels of out_proj are 11 panels = 33 tiles for 32 workgroups on five of the XCDs - a second round for one tile.  bf16
   // keeps it: there the chip is power- and bandwidth-limited and a partial round costs nothing measurable.)
-  constexpr bool kRR = sizeof(T) == 4 && ABL != 2;
+  const bool kRR = sizeof(T) == 4 && ABL != 2 && g.order != 1;   // (g.order: 0 / 2 = round robin, 1 = XCD panel ranges)
   const int qd_ = G >> 3, rd_ = G & 7;
   const int wk = (xcd < rd_ ? xcd * (qd_ + 1) : rd_ * (qd_ + 1) + (xcd - rd_) * qd_) + pos;
   // this workgroup's tiles, numbered 0 .. nh + ntw - 1: nh head tiles, then ntw tail tiles (tail tile numbers wk, wk + G, ...)
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // tile number `c` of this workgroup: first row, first column, height in 64-row units
   auto tile_at = [&](int c, int& m0, int& n0, int& hq) {
     if (!BAL || c < nh) {
-      if constexpr (kRR) {
+      if (kRR) {
         const int lt = wk + c * G;
         const int tm = lt / tilesN;
         m0 = tm * BM;
@@ -598,15 +598,19 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
       offB[i] = (unsigned)gr * (unsigned)(g.ldw * (int)sizeof(T)) + swz;
     }
   };
-  // activation piece i of a wave covers rows (wave + i NW) 8 ..: unit i NW / 8 of the tile; a lower tile does not stage it
-  auto a_piece_staged = [&](int i) { return !BAL || (i * NW) / 8 < hq_ld; };
-  auto stage_load = [&](int stage, int kt) {
+  // activation piece i of a wave covers rows (wave + i NW) 8 ..: unit i NW / 8 of the tile; a lower tile need not stage it.
+  // SKIP is a property of the CODE that issues the piece, not of the tile: the full-height body stages every piece
+  // unconditionally (no compare + branch per piece in its K loop; measured neutral either way) - also when the K-tiles belong to
+  // the first tail tile (rows past its height are clamped to valid addresses and never read); only the tail body and the
+  // prologue leave the unused pieces out.
+  auto a_piece_staged = [&](int i, auto SKIP) { return !decltype(SKIP)::value || (i * NW) / 8 < hq_ld; };
+  auto stage_load = [&](int stage, int kt, auto SKIP) {
     kt += rot;
     if (kt >= nk) kt -= nk;
     char* dst = smem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
-      if (a_piece_staged(i))
+      if (a_piece_staged(i, SKIP))
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * ROWB)),
             (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
@@ -618,13 +622,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   };
   // One LDS-DMA piece of a stage (idx < LPA: activation rows, else weight rows): lets the K loop spread the pieces of a
   // K-tile over its MFMA groups instead of issuing them in one burst.
-  auto stage_piece = [&](int stage, int kt, auto IDX) {
+  auto stage_piece = [&](int stage, int kt, auto IDX, auto SKIP) {
     constexpr int idx = decltype(IDX)::value;
     kt += rot;
     if (kt >= nk) kt -= nk;
     char* dst = smem + stage * STAGE + wave * 1024;
     if constexpr (idx < LPA) {
-      if (a_piece_staged(idx))
+      if (a_piece_staged(idx, SKIP))
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * ROWB)),
             (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
@@ -654,8 +658,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   int m0, n0;
   tile_sources(0, m0, n0);
   bias_load(0, n0);
-  stage_load(0, 0);
-  stage_load(1, 1);
+  stage_load(0, 0, std::bool_constant<BAL>{});
+  stage_load(1, 1, std::bool_constant<BAL>{});
   int foff[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) foff[s] = ((((sizeof(T) == 2) ? (4 * s + q) : (q + 4 * s)) ^ f) * 16);
@@ -678,6 +682,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     constexpr int NG = FMq;         // MFMA groups per K-tile: 2 k-substeps x HQ row-fragment pairs, 2*FN MFMAs each
     constexpr int GPS = HQ;         // groups per k-substep
     constexpr int TMq = 32 * HQ;    // rows per wave row
+    constexpr std::bool_constant<(BAL && HQ < HQF)> kSkip{};   // (see a_piece_staged)
     // the accumulators start from the bias slice of this tile (in LDS since the hand-over that published K-tile 0)
     f32x4 acc[FMq][FN];
     {
@@ -735,7 +740,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
           if (ABL != 1) {
             if (kt + 2 < nk) {
               static_for<LPW>([&](auto I) {
-                if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) < 0) stage_piece(sidx, kt + 2, I);
+                if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) < 0) stage_piece(sidx, kt + 2, I, kSkip);
               });
             } else if (has_next) {
               if (kt + 2 == nk) {
@@ -745,10 +750,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
                 // what matters here is only that every piece of its K-tile 0 is issued exactly once: the pieces that
                 // do not go out here follow after this tile's groups in the last K-step, same predicate)
                 static_for<LPW>([&](auto I) {
-                  if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) < 0) stage_piece(sidx, 0, I);
+                  if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) < 0) stage_piece(sidx, 0, I, kSkip);
                 });
               } else {
-                stage_load(sidx, 1);  // always a burst: it has to be older than the epilogue stores (counted vmcnt)
+                stage_load(sidx, 1, kSkip);  // always a burst: it has to be older than the epilogue stores (counted vmcnt)
               }
             }
           }
@@ -791,7 +796,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
             if (kt > 0 && (kt + 1 < nk || has_next)) {
               const int lk = kt + 1 < nk ? kt + 1 : 0;
               static_for<LPW>([&](auto I) {
-                if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) == u) stage_piece(sidx ^ 1, lk, I);
+                if constexpr (piece_slot_in(SCHED, decltype(I)::value, NG) == u) stage_piece(sidx ^ 1, lk, I, kSkip);
               });
             }
           }

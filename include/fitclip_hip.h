@@ -9,9 +9,11 @@
  *   - plain pointers and sizes only; every pointer marked "dev" is DEVICE memory owned by the caller (PyTorch-ROCm
  *     tensors: pass `tensor.data_ptr()`); the library allocates no device memory and never synchronises.
  *   - every launch goes to the `hipStream_t` passed in (`torch.cuda.current_stream().cuda_stream`); all functions
- *     may be captured into a hipGraph.
+ *     may be captured into a hipGraph (tests/test_gpu_graph.py: the whole encode-and-score call, replayed bitwise).
  *   - return 0 on success, a negative fc_status otherwise; `fc_last_error()` returns a thread-local message.
- *   - one handle per device / model; handles are independent (no global state besides the error string).
+ *   - one handle per device / model; handles are independent (no global state besides the thread-local error string and
+ *     per-device caches of two device attributes: the compute-unit count and which kernels had their dynamic-LDS limit
+ *     raised); the library reads no environment variable.
  *   - layouts: row-major, fp32 unless stated; video frames NCHW fp32 (the layout the reference's eval transform
  *     produces, clip_video_text_encoder.py:125-133); token ids int64 [n, context_length] (clip.tokenize output).
  */
