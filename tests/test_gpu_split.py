@@ -287,3 +287,22 @@ def test_gemm_split3_race_screen():
         for epi in (ops.EPI_BIAS_F32, ops.EPI_GELU_X3):
             assert torch.equal(ops.gemm_split3(a3, w3, bias, epi), first[epi]), (i, epi)
         assert torch.equal(ops.gemm_split3(other_a, other_w, other_b), first_other), i
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible devices")
+def test_second_device_gets_its_own_launch_attributes():
+    """Launch attributes are per (device, kernel): the dynamic-LDS limit of the large kernels and the CU count that sizes the
+    persistent grids.  A process that first ran on device 0 must produce the same bits on device 1 (round 3 cached both in
+    function-local statics of the split attention: the second device's launch failed or used the wrong grid)."""
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(3 * 197, 3 * 2 * 64, generator=g)
+    a, w, bias = torch.randn(25216, 768, generator=g), torch.randn(768, 768, generator=g) * 768 ** -0.5, torch.randn(768, generator=g)
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        with torch.cuda.device(dev):
+            o = ops.attention(qkv.to(dev), 3, 197, 2, split=True)
+            c = ops.gemm(a.to(dev), w.to(dev), bias.to(dev), ops.EPI_BIAS_T, tile=3)
+            c3 = ops.gemm_split3(ops.split3(a.to(dev)), ops.split3(w.to(dev)), bias.to(dev))
+            outs.append((o.cpu(), c.cpu(), c3.cpu()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
