@@ -108,10 +108,16 @@ int launch_pipelined(const GemmArgs& a, int forced_ht, hipStream_t stream) {
 }
 
 template <typename T>
-bool pipelined_ok(const GemmArgs& a) {
+bool pipelined_ok(const GemmArgs& a, int epi = EPI_BIAS_T) {
   const int esz = (int)sizeof(T);
-  return a.K / (ROWB / esz) >= 3 && a.N % 8 == 0 && (a.ldc * esz) % 16 == 0 && a.ldc % 4 == 0 && a.bias != nullptr &&
-         ((uintptr_t)a.bias & 15) == 0 && (size_t)256 * a.lda * esz < (1ull << 32) &&
+  if (epi == EPI_PATCH_F32) {  // the gathering loader: fp32 frames, patch size 8 / 16 / 32 (gemm_kernel.h, kPatch)
+    if (esz != 4 || a.gR <= 0 || !(a.gP == 8 || a.gP == 16 || a.gP == 32) || a.bias != nullptr ||
+        (size_t)6 * a.gR * a.gR * 4 >= (1ull << 31))
+      return false;
+  } else if (a.bias == nullptr || ((uintptr_t)a.bias & 15) != 0 || (size_t)256 * a.lda * esz >= (1ull << 32)) {
+    return false;
+  }
+  return a.K / (ROWB / esz) >= 3 && a.N % 8 == 0 && (a.ldc * esz) % 16 == 0 && a.ldc % 4 == 0 &&
          (size_t)a.N * a.ldw * esz < (1ull << 32);
 }
 
@@ -120,9 +126,10 @@ constexpr bool small_ring_epilogue(int epi) { return epi == EPI_BIAS_T || epi ==
 template <typename T>
 int resolve_tile(int epi, const GemmArgs& a, int tile) {
   if (tile != 0) return tile;
-  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || epi == EPI_RESID_F32 || (epi == EPI_DGELU_T && sizeof(T) == 4);
+  const bool has_pipelined = epi == EPI_BIAS_T || epi == EPI_GELU_T || epi == EPI_RESID_F32 ||
+                             ((epi == EPI_DGELU_T || epi == EPI_PATCH_F32) && sizeof(T) == 4);
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a)) return 3;
+  if (has_pipelined && t256 >= 192 && pipelined_ok<T>(a, epi)) return 3;
   // small fp32 block GEMMs (the text tower of an eval batch: 32 captions = 2464 rows, the N = 512 projections 80 tiles of
   // 128 x 128 for 256 CUs): 64 x 64 tiles on a four-stage ring (gemm_kernel.h, NSTG) while the 128 x 128 tiles would not fill
   // 2.5 rounds.  tools/text_gemm_probe.py, us per launch 128 x 128 -> ring: 32 captions out_proj 39 -> 22, c_proj 136 -> 76, c_fc
@@ -139,11 +146,12 @@ template <typename T, int EPI>
 int launch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   const int forced_ht = tile >= 4 && tile <= 7 ? tile - 4 : -1;
   if (tile >= 4 && tile <= 7) tile = 3;
-  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4);
+  constexpr bool kHasPipelined = EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 ||
+                                 ((EPI == EPI_DGELU_T || EPI == EPI_PATCH_F32) && sizeof(T) == 4);
   tile = resolve_tile<T>(EPI, a, tile);
   if (tile == 3) {
     if constexpr (kHasPipelined) {
-      if (!pipelined_ok<T>(a)) return fail(FC_EINVAL, "gemm: shape not supported by the pipelined kernel");
+      if (!pipelined_ok<T>(a, EPI)) return fail(FC_EINVAL, "gemm: shape not supported by the pipelined kernel");
       return launch_pipelined<T, EPI>(a, forced_ht, stream);
     } else {
       return fail(FC_EINVAL, "gemm: the pipelined kernel has no epilogue %d", EPI);

@@ -474,9 +474,17 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   static_assert(WM == 2 && BM % 64 == 0, "a tile is cut in 64-row units, 32 rows of each per wave row");
   static_assert(RG % NW == 0 && BN <= 256 && (!kStaged || TN == 64 || TN == 128), "tile");
   static_assert(kStaged ? NW * PATCH <= NW * 2048 : (TN % 32 == 0 && FN % 2 == 0), "output patch");
-  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 || (EPI == EPI_DGELU_T && sizeof(T) == 4), "epilogue");
+  static_assert(EPI == EPI_BIAS_T || EPI == EPI_GELU_T || EPI == EPI_RESID_F32 ||
+                ((EPI == EPI_DGELU_T || EPI == EPI_PATCH_F32) && sizeof(T) == 4), "epilogue");
   constexpr bool BAL = HT > 0;
   static_assert(!BAL || (NW == 8 && BM == 256 && HT < HQF), "tail tiles: 8 waves, one LDS-DMA piece per wave and 64-row unit");
+  // EPI_PATCH_F32 (fp32, round 4): the patch embedding.  A is the FRAMES tensor f32 [n, 3, gR, gR]: row m = (image, patch), column
+  // k = (channel, py, px); the LDS-DMA loader gathers the 16-byte pieces (4 pixels of a patch row) itself, as gemm_kernel does:
+  // a lane's piece of K-tile kt sits at [tile's first image] + [its (image, patch, chunk) offset, 32 bits] + [a K-tile term that
+  // only depends on kt: channel and first patch row].  Patch sizes 8, 16, 32 (a K-tile of 32 floats is 4, 2 or 1 patch rows and
+  // K-tiles per channel is a power of two).  No bias, natural K order (the bits of gemm_kernel's patch epilogue); the epilogue
+  // adds the positional embedding and skips the CLS row of every image.
+  constexpr bool kPatch = EPI == EPI_PATCH_F32;
   // the counted wait behind the epilogue stores needs LPW + NST to fit the 6-bit vmcnt; tilings with more stores per wave
   // (4 waves of 128x128) wait for everything at the first hand-over of the next tile instead
   constexpr bool kCounted = LPW + NST < 64;
@@ -581,21 +589,44 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     const int rin = lane_s >> 3, pc = lane_s & 7;
     const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
     a_base_ld = (wm * 32 * hq_ld + (lane_s & 15)) * ROWB;
-    if constexpr (ROT == 1) rot = (n0 >> 8) % nk;  // a function of the output column block only
+    if constexpr (ROT == 1 && !kPatch) rot = (n0 >> 8) % nk;  // a function of the output column block only
     // activation rows: a 64-bit tile base + 32-bit offsets inside the tile (the 4w-wide MLP rows of a 2048-frame fp32 pass are
     // 5 GB; the weight stays below 4 GiB)
     const int mb = ABL == 2 ? 0 : m0;
-    a_tile = reinterpret_cast<const char*>(g.A) + (size_t)mb * ((size_t)g.lda * sizeof(T));
+    if constexpr (kPatch) {
+      const int img0 = mb / g.P, Gp = g.gR / g.gP;
+      const int lch4 = (int)(swz >> 4) * 4;                       // first float of this lane's logical chunk inside a K-tile
+      const int py_off = lch4 / g.gP, px = lch4 - py_off * g.gP;
+      a_tile = reinterpret_cast<const char*>(g.A) + (size_t)img0 * 3 * g.gR * g.gR * sizeof(float);
 #pragma unroll
-    for (int i = 0; i < LPA; ++i) {
-      const int row = min((wave + i * NW) * 8 + rin, g.M - 1 - mb);
-      offA[i] = (unsigned)row * (unsigned)(g.lda * (int)sizeof(T)) + swz;
+      for (int i = 0; i < LPA; ++i) {
+        const int gm = mb + min((wave + i * NW) * 8 + rin, g.M - 1 - mb);
+        const int img = gm / g.P, pidx = gm - img * g.P, gy = pidx / Gp, gx = pidx - gy * Gp;
+        offA[i] = (unsigned)((((img - img0) * 3 * g.gR + gy * g.gP + py_off) * g.gR + gx * g.gP + px) * (int)sizeof(float));
+      }
+    } else {
+      a_tile = reinterpret_cast<const char*>(g.A) + (size_t)mb * ((size_t)g.lda * sizeof(T));
+#pragma unroll
+      for (int i = 0; i < LPA; ++i) {
+        const int row = min((wave + i * NW) * 8 + rin, g.M - 1 - mb);
+        offA[i] = (unsigned)row * (unsigned)(g.lda * (int)sizeof(T)) + swz;
+      }
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
       const int row = (wave + i * NW) * 8 + rin;
       const int gr = min((ABL == 2 ? 0 : n0) + row, g.N - 1);
       offB[i] = (unsigned)gr * (unsigned)(g.ldw * (int)sizeof(T)) + swz;
+    }
+  };
+  // byte offset of K-tile kt inside an activation row (patch gather: channel c = kt / (K-tiles per channel), first patch row)
+  const int kpc_shift = kPatch ? 31 - __builtin_clz((unsigned)max(1, g.gP * g.gP / BKE)) : 0;
+  auto a_koff = [&](int kt) -> unsigned {
+    if constexpr (kPatch) {
+      const int c = kt >> kpc_shift, py0 = (kt - (c << kpc_shift)) * (BKE / g.gP);
+      return (unsigned)((c * g.gR + py0) * g.gR * (int)sizeof(float));
+    } else {
+      return (unsigned)kt * ROWB;
     }
   };
   // activation piece i of a wave covers rows (wave + i NW) 8 ..: unit i NW / 8 of the tile; a lower tile need not stage it.
@@ -612,7 +643,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     for (int i = 0; i < LPA; ++i)
       if (a_piece_staged(i, SKIP))
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + (unsigned)kt * ROWB)),
+            (const __attribute__((address_space(1))) void*)(a_tile + (offA[i] + a_koff(kt))),
             (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
@@ -630,7 +661,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
     if constexpr (idx < LPA) {
       if (a_piece_staged(idx, SKIP))
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * ROWB)),
+            (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + a_koff(kt))),
             (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
     } else {
       __builtin_amdgcn_global_load_lds(
@@ -645,7 +676,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
   // both be in that burst, with nobody feeding the matrix pipe.
   static_assert(SCHED == 0 || LPW == 8, "piece schedules are written for 8 pieces per wave");
   auto bias_load = [&](int buf, int n0) {  // BN floats -> LDS by one LDS-DMA of wave 0 (part of that tile's first load)
-    if (wave == 0) {
+    if (!kPatch && wave == 0) {
       const float* p = g.bias + min(n0 + lane * 4, g.N - 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                        (__attribute__((address_space(3))) void*)(smem + OFF_BIAS + buf * 1024), 16, 0,
@@ -689,7 +720,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
       const float* biasb = reinterpret_cast<const float*>(smem + OFF_BIAS + (it & 1) * 1024) + wn * TN + 4 * q;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(biasb + j * 16);
+        const f32x4 b = kPatch ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(biasb + j * 16);
 #pragma unroll
         for (int i = 0; i < FMq; ++i) acc[i][j] = b;
       }
@@ -916,7 +947,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
               if constexpr (EPI == EPI_RESID_F32) val = xres[i % RWIN][jj][h] + val;
               const int mo = cm0 + wm * TMq + i * 16 + row, no = cn0 + wn * TN + jj * 32 + rch * 4;
               if (interior || (mo < g.M && no < g.N)) {
-                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<TOUT*>(g.C) + (size_t)mo * g.ldc + no);
+                size_t orow = (size_t)mo;
+                if constexpr (kPatch) {  // token row of (image, patch): the image's CLS row is skipped; + positional embedding
+                  const int img = mo / g.P, prow = mo - img * g.P + 1;
+                  orow = (size_t)img * (g.P + 1) + prow;
+                  val += *reinterpret_cast<const f32x4*>(g.aux + (size_t)prow * g.N + no);
+                }
+                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<TOUT*>(g.C) + orow * g.ldc + no);
                 if constexpr (ABL == 4) *dst = val;  // lab: write-back instead of non-temporal stores
                 else __builtin_nontemporal_store(val, dst);
               }
