@@ -213,6 +213,28 @@ def test_similarity_ranks_equal_the_materialised_path(nt, nv, dim, offset):
     assert ops.similarity_ranks(ti.to(DEV), vi.to(DEV), offset).tolist() == want.tolist()
 
 
+def test_row_cut_on_random_shapes():
+    """Forty random problems (M up to 60 000 rows, N a multiple of 8 up to 3072, K a multiple of 32 from the pipelined kernel's
+    minimum up to 1024; seeded): whatever head / tail the planner picks (`ops.gemm_plan`), and under every forced tail height,
+    the persistent kernel's rows equal the plain 128 x 128 kernel's bit for bit - residual epilogue (read-modify-write: a row
+    touched twice or not at all would show)."""
+    rng = np.random.default_rng(7)
+    seen = set()
+    for _ in range(40):
+        M = int(rng.integers(1, 60000))
+        N = int(rng.integers(1, 385)) * 8
+        K = int(rng.integers(3, 33)) * 32
+        a, w, bias = _rand(M, K, seed=M).to(DEV), _rand(N, K, seed=N, scale=K ** -0.5).to(DEV), _rand(N, seed=K).to(DEV)
+        resid = _rand(M, N, seed=1).to(DEV)
+        want = ops.gemm(a, w, bias, ops.EPI_RESID_F32, out=resid.clone(), tile=1)
+        hp, ht = ops.gemm_plan(M, N, K)
+        seen.add(ht)
+        for tile in (3, 5 + int(rng.integers(0, 3))):
+            got = ops.gemm(a, w, bias, ops.EPI_RESID_F32, out=resid.clone(), tile=tile)
+            assert torch.equal(got, want), (M, N, K, tile, hp, ht)
+    assert len(seen) >= 3, seen   # the planner used several cuts over the sample
+
+
 def test_new_gemm_paths_at_the_edges():
     """Ragged and tiny problems through every fp32 kernel of the block epilogues: fewer rows than one 64-row unit, rows that end
     inside a unit, one column tile, K at the pipelined kernel's minimum (3 K-tiles) - forced row cuts (tiles 4..7), the 64 x 64
