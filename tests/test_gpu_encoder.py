@@ -668,6 +668,12 @@ def test_bench_config_c5_split_step_rehearsal():
     assert split["losses"][0] == plain["losses"][0]
     assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(split["losses"], plain["losses"]))
     assert split["roofline"]["executed_flops_per_step"] > split["roofline"]["flops_per_step"]
+    # ... and on two ranks (5 + 5 clips): the gradient exchange happens once, in the last micro-batch's backward
+    two_split = _run(common + ["--gpus", "2", "--backend", "gloo", "--keep-clips", "1", "--micro-clips", "2"])
+    two_plain = _run(common + ["--gpus", "2", "--backend", "gloo"])
+    assert two_split["split_step"]["recomputed_clips"] == 4 and two_plain["split_step"] is None
+    assert two_split["losses"][0] == two_plain["losses"][0]
+    assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(two_split["losses"], two_plain["losses"]))
 
 
 def test_bench_exits_nonzero_when_a_secondary_leg_fails():
