@@ -23,13 +23,19 @@ def main() -> None:
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tiles", default="1,2")
+    ap.add_argument("--only", default="", help="comma list of shape names (default: all four)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.precision == "bf16" else torch.float32
     M = args.frames * 197
     shapes = [("qkv", 2304, 768, ops.EPI_BIAS_T), ("out_proj", 768, 768, ops.EPI_RESID_F32),
-              ("c_fc", 3072, 768, ops.EPI_GELU_T), ("c_proj", 768, 3072, ops.EPI_RESID_F32)]
+              ("c_fc", 3072, 768, ops.EPI_GELU_T), ("c_proj", 768, 3072, ops.EPI_RESID_F32),
+              # (lab: the projections' shapes without the residual read - only with --only)
+              ("out_proj_bias", 768, 768, ops.EPI_BIAS_T), ("c_proj_bias", 768, 3072, ops.EPI_BIAS_T)]
     g = torch.Generator(device="cuda").manual_seed(0)
+    only = [x for x in args.only.split(",") if x]
     for name, N, K, epi in shapes:
+        if (only and name not in only) or (not only and name.endswith("_bias")):
+            continue
         a = torch.randn((M, K), generator=g, device="cuda").to(dt)
         w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dt)
         bias = torch.randn((N,), generator=g, device="cuda")
