@@ -174,16 +174,14 @@ int launch_kd_loss(const float* scores, const float* teacher, int rows, int cols
 // attention backward (attention_bwd.hip); qkv / o are the forward's input / output, d_o the gradient of o
 int launch_attention_backward(int precision, const void* qkv, const void* o, const void* d_o, void* dqkv, int n_seq,
                               int S, int heads, int causal, hipStream_t stream);
-// C[N1, N2] = beta C + alpha sum_m A[m, N1] B[m, N2]  (wgrad.hip; fp32).  a_skip > 0: A row m lives at m + m / a_skip + 1
+// C[N1, N2] = beta C + alpha sum_m A[m, N1] B[m, N2]  (wgrad.hip; fp32).  a_skip > 0: A row m lives at m + m / a_skip + 1;
+// colsum: null, or [N1]: beta colsum + sum_m A[m, N1] from the same pass (the bias gradient next to the weight gradient)
 size_t gemm_tn_scratch_bytes(int M, int N1, int N2);
 int launch_gemm_tn(const float* A, const float* B, int M, int N1, int N2, int lda, int ldb, int a_skip, float alpha,
                    float beta, float* C, int ldc, float* scratch, size_t scratch_bytes, const float* zeros,
-                   hipStream_t st);
+                   hipStream_t st, float* colsum = nullptr);
 int launch_reduce_partials(const float* P, int splits, int rows, int cols, float* C, int ldc, float alpha, float beta,
                            hipStream_t st);
-size_t colsum_scratch_bytes(int rows, int cols);
-int launch_colsum(const void* X, int kind, long ldx, int rows, int cols, float* out, float beta, float* scratch,
-                  size_t scratch_bytes, hipStream_t st);
 // backward.hip
 size_t layernorm_bwd_scratch_bytes(int D);
 int launch_layernorm_backward(const float* x, long x_stride, const int* gather, const void* dy, int dy_kind,

@@ -107,7 +107,7 @@ Scratch carve_scratch(const fc_handle* h, int tower, int n, char* base) {
   if (tower == 0) tn = std::max(tn, gemm_tn_scratch_bytes(n * h->patches(), d.w, h->patch_k()));
   s.tn_bytes = tn;
   s.tn = take(tn);
-  s.small_bytes = std::max({colsum_scratch_bytes(Mi, 4 * d.w), layernorm_bwd_scratch_bytes(d.w), (size_t)d.S * w * 4});
+  s.small_bytes = std::max(layernorm_bwd_scratch_bytes(d.w), (size_t)d.S * w * 4);
   s.small = take(s.small_bytes);
   if (tower == 1) {
     s.tok_bytes = token_grad_scratch_bytes(Mi, h->cfg.vocab_size);
@@ -178,11 +178,10 @@ struct GradCtx {
   float beta;
   hipStream_t st;
   float* grad(const std::string& n) const { return h->grad(n); }
-  int tn(const float* A, const float* B, int M, int N1, int N2, int lda, int ldb, int a_skip, float* C, int ldc) const {
-    return launch_gemm_tn(A, B, M, N1, N2, lda, ldb, a_skip, 1.f, beta, C, ldc, sc.tn, sc.tn_bytes, h->zeros, st);
-  }
-  int colsum(const float* X, int rows, int cols, float* out) const {
-    return launch_colsum(X, PREC_F32, cols, rows, cols, out, beta, sc.small, sc.small_bytes, st);
+  // dW = A^T B (A = dY), and with `bias` the bias gradient = column sums of dY from the same pass over it
+  int tn(const float* A, const float* B, int M, int N1, int N2, int lda, int ldb, int a_skip, float* C, int ldc,
+         float* bias = nullptr) const {
+    return launch_gemm_tn(A, B, M, N1, N2, lda, ldb, a_skip, 1.f, beta, C, ldc, sc.tn, sc.tn_bytes, h->zeros, st, bias);
   }
   int ln_bwd(const float* x, long xs, const int* gather, const float* dy, long dys, int dy_compact, const float* gamma,
              float* out, long os, int acc, int rows, int D, float* dgamma, float* dbeta) const {
@@ -202,20 +201,16 @@ int backward_blocks(const GradCtx& c, const Tower& t, const std::string& prefix,
     const Layer& s = a.layers[l];
     const BlockNames nm = block_names(prefix, l);
     // ---- MLP branch: x_out = x_mid + c_proj(quickgelu(c_fc(LN2(x_mid))))
-    FC_TRY(c.colsum(sc.g, M, w, c.grad(nm.proj_b)));
-    FC_TRY(c.tn(sc.g, s.hact, M, w, 4 * w, w, 4 * w, 0, c.grad(nm.proj_w), 4 * w));
+    FC_TRY(c.tn(sc.g, s.hact, M, w, 4 * w, w, 4 * w, 0, c.grad(nm.proj_w), 4 * w, c.grad(nm.proj_b)));
     FC_TRY(gemm_f32(EPI_DGELU_T, sc.g, b.proj_wT, zeros, sc.dA, s.hpre, M, 4 * w, w, 4 * w, 0, c.st));  // d pre-activation
-    FC_TRY(c.colsum(sc.dA, M, 4 * w, c.grad(nm.fc_b)));
-    FC_TRY(c.tn(sc.dA, s.xn2, M, 4 * w, w, 4 * w, w, 0, c.grad(nm.fc_w), w));
+    FC_TRY(c.tn(sc.dA, s.xn2, M, 4 * w, w, 4 * w, w, 0, c.grad(nm.fc_w), w, c.grad(nm.fc_b)));
     FC_TRY(gemm_f32(EPI_BIAS_T, sc.dA, b.fc_wT, zeros, sc.dB, nullptr, M, w, 4 * w, w, 0, c.st));       // d LN2 output
     FC_TRY(c.ln_bwd(s.x_mid, w, nullptr, sc.dB, w, 0, b.ln2_w, sc.g, w, 1, M, w, c.grad(nm.ln2_w), c.grad(nm.ln2_b)));
     // ---- attention branch: x_mid = x_in + out_proj(attention(in_proj(LN1(x_in))))
-    FC_TRY(c.colsum(sc.g, M, w, c.grad(nm.out_b)));
-    FC_TRY(c.tn(sc.g, s.ao, M, w, w, w, w, 0, c.grad(nm.out_w), w));
+    FC_TRY(c.tn(sc.g, s.ao, M, w, w, w, w, 0, c.grad(nm.out_w), w, c.grad(nm.out_b)));
     FC_TRY(gemm_f32(EPI_BIAS_T, sc.g, b.out_wT, zeros, sc.dB, nullptr, M, w, w, w, 0, c.st));           // d attention out
     FC_TRY(launch_attention_backward(PREC_F32, s.qkv, s.ao, sc.dB, sc.dA, d.n, d.S, d.heads, d.causal, c.st));
-    FC_TRY(c.colsum(sc.dA, M, 3 * w, c.grad(nm.in_b)));
-    FC_TRY(c.tn(sc.dA, s.xn1, M, 3 * w, w, 3 * w, w, 0, c.grad(nm.in_w), w));
+    FC_TRY(c.tn(sc.dA, s.xn1, M, 3 * w, w, 3 * w, w, 0, c.grad(nm.in_w), w, c.grad(nm.in_b)));
     FC_TRY(gemm_f32(EPI_BIAS_T, sc.dA, b.in_wT, zeros, sc.dB, nullptr, M, w, 3 * w, w, 0, c.st));       // d LN1 output
     FC_TRY(c.ln_bwd(s.x_in, w, nullptr, sc.dB, w, 0, b.ln1_w, sc.g, w, 1, M, w, c.grad(nm.ln1_w), c.grad(nm.ln1_b)));
   }

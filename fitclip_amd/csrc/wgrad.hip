@@ -30,6 +30,7 @@ struct TnArgs {
   const float* A;
   const float* B;
   float* P;            // [splits, N1, N2] partials
+  float* CS;           // null, or [splits, N1]: per-split column sums of A (the bias gradient next to the weight gradient)
   const float* zeros;  // >= 256 floats of zeros (device)
   int M, N1, N2, lda, ldb;
   int rows_per_split;  // multiple of TN_BK
@@ -54,43 +55,70 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_tn_kernel(const TnArgs g) {
   const int tiles2 = (g.N2 + BN2 - 1) / BN2;
   const int tiles = ((g.N1 + BN1 - 1) / BN1) * tiles2;
   const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+  // (numbering the workgroups XCD-major, so that the sharers of an A / B slab sit behind one L2, measured nothing: the kernel
+  // is not waiting for its operands: with neither LDS-DMA nor operand reads in the loop it is 4 % faster, tools/tn_bench.py)
   const int n1_0 = (tile / tiles2) * BN1, n2_0 = (tile % tiles2) * BN2;
   const int m_begin = split * g.rows_per_split;
   const int m_end = min(g.M, m_begin + g.rows_per_split);
 
-  // ---- per-lane staging plan: piece p covers floats [256 p, 256 p + 256) of the stage image [A rows | B rows]
-  int prow[LPW], pcol[LPW];
-  bool isb[LPW];
+  // ---- per-lane staging plan: piece p covers floats [256 p, 256 p + 256) of the stage image [A rows | B rows].  The steps
+  // are staged strictly in order, so every piece keeps a running 32-bit byte offset from its operand's row m_begin (uniform
+  // 64-bit base), the rows it has left before m_end, and - for an A operand stored with skipped rows - m mod a_skip: a step
+  // costs a handful of adds and selects per piece (the first version recomputed row, division and a branch per piece).
+  static_assert(BN1 == BN2 && (PIECES / 2) % NW == 0, "the first LPW / 2 pieces of a wave are A rows, the others B rows");
+  constexpr int LPA = LPW / 2;
+  const int skip = g.a_skip;
+  const size_t a_row0 = skip > 0 ? (size_t)m_begin + m_begin / skip + 1 : (size_t)m_begin;
+  const char* a_base = reinterpret_cast<const char*>(g.A + a_row0 * g.lda);
+  const char* b_base = reinterpret_cast<const char*>(g.B + (size_t)m_begin * g.ldb);
+  const int step_q = skip > 0 ? TN_BK / skip : 0, step_r = skip > 0 ? TN_BK % skip : 0;
+  unsigned poff[LPW];
+  int pleft[LPA], prem[LPA];   // (A piece i and B piece LPA + i cover the same m-row)
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    const int o = (wave + i * NW) * 256 + lane * 4;
-    isb[i] = o >= TN_BK * BN1;
-    const int oo = isb[i] ? o - TN_BK * BN1 : o;
-    const int bn = isb[i] ? BN2 : BN1;
-    prow[i] = oo / bn;
-    const int pc = oo - prow[i] * bn;
-    const int lc = pc ^ ((prow[i] & 1) << 4);  // logical column held at this physical position
-    const int n0 = isb[i] ? n2_0 : n1_0, nmax = isb[i] ? g.N2 : g.N1;
-    pcol[i] = min(n0 + lc, nmax - 4);          // columns past the edge re-read the last chunk (never stored)
+    const bool isb = i >= LPA;
+    const int oo = (wave + (i - (isb ? LPA : 0)) * NW) * 256 + lane * 4;
+    const int prow = oo / BN1;
+    const int pc = oo - prow * BN1;
+    const int lc = pc ^ ((prow & 1) << 4);  // logical column held at this physical position
+    const int col = min((isb ? n2_0 : n1_0) + lc, (isb ? g.N2 : g.N1) - 4);  // columns past the edge re-read the last chunk (never stored)
+    if (!isb) pleft[i] = m_end - (m_begin + prow);
+    if (isb) {
+      poff[i] = (unsigned)prow * (unsigned)(g.ldb * 4) + (unsigned)col * 4u;
+    } else {
+      int rows = prow;
+      if (skip > 0) {
+        const int rem = m_begin % skip + prow;  // (one exact division per piece, once)
+        rows += rem / skip;
+        prem[i] = rem % skip;
+      } else {
+        prem[i] = 0;
+      }
+      poff[i] = (unsigned)rows * (unsigned)(g.lda * 4) + (unsigned)col * 4u;
+    }
   }
-  auto stage_load = [&](int stage, int m0) {
+  auto stage_next = [&](int stage) {   // the next TN_BK rows -> `stage`
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
-      const int m = m0 + prow[i];
-      const float* src;
-      if (m < m_end) {
-        if (isb[i]) {
-          src = g.B + (size_t)m * g.ldb + pcol[i];
-        } else {
-          const size_t r = g.a_skip > 0 ? (size_t)m + m / g.a_skip + 1 : (size_t)m;
-          src = g.A + r * g.lda + pcol[i];
-        }
-      } else {
-        src = g.zeros + lane * 4;  // a zero A row kills the product; B rows are zeroed as well
-      }
+      const bool isb = i >= LPA;
+      const char* real = (isb ? b_base : a_base) + poff[i];
+      const char* src = pleft[isb ? i - LPA : i] > 0 ? real : reinterpret_cast<const char*>(g.zeros + lane * 4);  // a zero row kills the product
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(lds + stage * STAGE_F + (wave + i * NW) * 256),
                                        16, 0, 0);
+      if (isb) pleft[i - LPA] -= TN_BK;   // (after both pieces of the row)
+      if (isb) {
+        poff[i] += (unsigned)(TN_BK * g.ldb * 4);
+      } else {
+        int adv = TN_BK + step_q;
+        if (skip > 0) {
+          prem[i] += step_r;
+          const bool wrap = prem[i] >= skip;
+          prem[i] -= wrap ? skip : 0;
+          adv += wrap ? 1 : 0;
+        }
+        poff[i] += (unsigned)adv * (unsigned)(g.lda * 4);
+      }
     }
   };
 
@@ -102,27 +130,97 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_tn_kernel(const TnArgs g) {
 
   const int r = lane & 15, q = lane >> 4;
   const int nsteps = (m_end - m_begin + TN_BK - 1) / TN_BK;
-  if (nsteps > 0) stage_load(0, m_begin);
+  // Software pipeline (the hand-over of gemm_pipelined_kernel): the LDS-DMA runs TWO steps ahead of the MFMAs, and the
+  // hand-over to step st + 1 - wait for its DMA (issued a whole step ago), barrier, DMA of step st + 2 into the stage
+  // everybody has just finished reading, first operand reads of step st + 1 - sits in FRONT of the last MFMA group of step
+  // st, which covers it.  (First version: wait + barrier + DMA burst + operand reads at the top of every step with the
+  // matrix pipe idle - 0.80-0.84 of peak.)  Every accumulator still sees its products in the same order: same bits.
+  constexpr int KS = TN_BK / 4;   // MFMA groups (k-slots of 4 m-rows) per step
+  static_assert(KS % 2 == 0, "the operand double buffer alternates per group");
+  float af[2][FM], bf[2][FN];
+  // column sums of A (dY): the workgroups of the first n2 tile hold every A element of their slab in registers once - their
+  // wn = 0 waves add them up (per lane: the m-rows of its k-slot, in step order; the four k-slots at the end)
+  const bool do_cs = g.CS != nullptr && tile % tiles2 == 0 && wn == 0;
+  float cs[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) cs[i] = 0.f;
+  // Operand addresses: FOUR byte offsets per lane (even / odd 16-column groups of A and of B) + immediates.  The bank swizzle
+  // flips bit 4 of the column on odd m-rows (q odd; 4 ks is even), and bit 4 of (tile column + 16 i + r) is the parity of i:
+  // the flip is + 16 columns for even i and - 16 for odd i, so column group i sits at (i even ? even : odd base) + 64 (i & ~1) bytes.
+  // A stage is a power of two bytes and LDS starts at 0: the other stage is one XOR away.
+  constexpr int STAGE_B = STAGE_F * 4;
+  static_assert((STAGE_B & (STAGE_B - 1)) == 0 && TM % 32 == 0 && TNN % 32 == 0, "stage toggle / swizzle parity");
+  const int swz = (q & 1) << 4;
+  // (the odd base includes group 1's 16 columns, so that it is never negative: odd i adds 64 (i - 1) bytes)
+  int rd_a[2] = {(q * BN1 + wm * TM + r + swz) * 4, (q * BN1 + wm * TM + r + 16 - swz) * 4};
+  int rd_b[2] = {(TN_BK * BN1 + q * BN2 + wn * TNN + r + swz) * 4, (TN_BK * BN1 + q * BN2 + wn * TNN + r + 16 - swz) * 4};
+  auto toggle_stage = [&]() {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rd_a[e] ^= STAGE_B, rd_b[e] ^= STAGE_B;
+  };
+  auto read_operands = [&](int ks, float (&a)[FM], float (&b)[FN]) {   // k-slot ks of the stage the offsets point into
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const float*>(smem + rd_a[i & 1] + ks * 4 * BN1 * 4 + (i & ~1) * 64);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const float*>(smem + rd_b[j & 1] + ks * 4 * BN2 * 4 + (j & ~1) * 64);
+  };
+  if (nsteps > 0) {
+    stage_next(0);
+    if (nsteps > 1) {
+      stage_next(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");   // step 0 has landed; step 1 may be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_operands(0, af[0], bf[0]);
+  }
   for (int st = 0; st < nsteps; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (st + 1 < nsteps) stage_load((st + 1) & 1, m_begin + (st + 1) * TN_BK);
-    const float* as = lds + (st & 1) * STAGE_F;
-    const float* bs = as + TN_BK * BN1;
 #pragma unroll
-    for (int ks = 0; ks < TN_BK / 4; ++ks) {
-      const int row = ks * 4 + q;              // m-row of this lane's k-slot
-      const int sw = (row & 1) << 4;
-      float af[FM], bf[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = as[row * BN1 + ((wm * TM + i * 16 + r) ^ sw)];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = bs[row * BN2 + ((wn * TNN + j * 16 + r) ^ sw)];
+    for (int ks = 0; ks < KS; ++ks) {
+      constexpr int kReads = FM + FN;
+      const int cur = ks & 1;                  // (KS is even: the parity carries over the step boundary)
+      if (ks + 1 < KS) {
+        read_operands(ks + 1, af[cur ^ 1], bf[cur ^ 1]);
+      } else {
+        if (st + 1 < nsteps) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this stage has returned ...
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and this wave's pieces of step st + 1 have landed
+          __builtin_amdgcn_s_barrier();                       // ... for every wave
+          asm volatile("" ::: "memory");
+          if (st + 2 < nsteps) stage_next(st & 1);
+        }
+        // UNCONDITIONALLY (after the last step they are never used): inside the branch the reads would sit in a basic block of
+        // their own in front of this group's first MFMA, and hipcc's lgkmcnt(0) for its operands would wait for them
+        toggle_stage();
+        read_operands(0, af[cur ^ 1], bf[cur ^ 1]);
+      }
       // X as the MFMA A-operand, dY as the B-operand: a lane then holds 4 CONSECUTIVE n2 of one n1 (16-byte stores)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) cs[i] += af[cur][i];
+      }
+      // issue order: ONE MFMA, then the operand reads of the next group, then the other MFMAs (hipcc's lgkmcnt(0) for this
+      // group's operands sits in front of the first MFMA: with the reads in front of it that wait would cover them too)
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - 1, 0);
+    }
+  }
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float v = cs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n1 = n1_0 + wm * TM + i * 16 + r;
+      if (q == 0 && n1 < g.N1) g.CS[(size_t)split * g.N1 + n1] = v;
     }
   }
   float* out = g.P + (size_t)split * g.N1 * g.N2;
@@ -144,43 +242,24 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* P, in
                                                               float* C, int ldc, float alpha, float beta) {
   const size_t n4 = plane / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    // (eight planes are requested before the first of them is added: a column sum comes here as up to 256 planes of a few KB,
+    // and one dependent load per plane was a 256-deep latency chain; the additions keep their order)
     f32x4 s = *reinterpret_cast<const f32x4*>(P + i * 4);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(P + (size_t)k * plane + i * 4);
+    int k = 1;
+    for (; k + 8 <= splits; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(k + u) * plane + i * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(P + (size_t)k * plane + i * 4);
     const size_t e = i * 4, row = e / cols, col = e - row * cols;
     f32x4* dst = reinterpret_cast<f32x4*>(C + row * ldc + col);
     f32x4 v = s * alpha;
     if (beta != 0.f) v += *dst * beta;
     *dst = v;
   }
-}
-
-// Column sums of X [rows, cols] (T): stage 1 writes P[chunk][cols] over row chunks; reduce_partials finishes.
-// Thread = 4 consecutive columns; a block covers 256 columns x its row chunk with 4 waves on interleaved rows.
-template <typename T>
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict__ X, long ldx, int rows, int cols,
-                                                             int rows_per_chunk, float* __restrict__ P) {
-  __shared__ f32x4 red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int strips = (cols + 255) / 256;
-  const int chunk = blockIdx.x / strips, strip = blockIdx.x - chunk * strips;
-  const int c = strip * 256 + lane * 4;
-  const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (c < cols) {
-    for (int row = r0 + wave; row < r1; row += 4) {
-      if constexpr (sizeof(T) == 4) {
-        s += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + (size_t)row * ldx + c);
-      } else {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(X) + (size_t)row * ldx + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += static_cast<float>(v[e]);
-      }
-    }
-  }
-  red[wave][lane] = s;
-  __syncthreads();
-  if (wave == 0 && c < cols)
-    *reinterpret_cast<f32x4*>(P + (size_t)chunk * cols + c) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 struct TnPlan {
@@ -215,7 +294,7 @@ int launch_tn_variant(const TnArgs& a, int blocks, hipStream_t st) {
 size_t gemm_tn_scratch_bytes(int M, int N1, int N2) {
   if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
   const TnPlan p = plan_tn(M, N1, N2);
-  return (size_t)p.splits * N1 * N2 * sizeof(float);
+  return (size_t)p.splits * N1 * (N2 + 4) * sizeof(float);   // (+ the column-sum partials, 16-byte aligned behind the tiles)
 }
 
 int launch_reduce_partials(const float* P, int splits, int rows, int cols, float* C, int ldc, float alpha, float beta,
@@ -230,9 +309,10 @@ int launch_reduce_partials(const float* P, int splits, int rows, int cols, float
   return FC_OK;
 }
 
+// colsum != nullptr: colsum[n1] = beta * colsum[n1] + sum_m A[m, n1] from the same pass over A (dY: the bias gradient)
 int launch_gemm_tn(const float* A, const float* B, int M, int N1, int N2, int lda, int ldb, int a_skip, float alpha,
                    float beta, float* C, int ldc, float* scratch, size_t scratch_bytes, const float* zeros,
-                   hipStream_t st) {
+                   hipStream_t st, float* colsum) {
   if (N1 <= 0 || N2 <= 0) return FC_OK;
   if (M <= 0) return fail(FC_EINVAL, "gemm_tn: M=%d", M);
   if (N1 % 4 || N2 % 4 || lda % 4 || ldb % 4 || ldc % 4 || lda < N1 || ldb < N2 || ldc < N2)
@@ -241,40 +321,21 @@ int launch_gemm_tn(const float* A, const float* B, int M, int N1, int N2, int ld
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)scratch | (uintptr_t)zeros) & 15 || !zeros || !scratch)
     return fail(FC_EINVAL, "gemm_tn: unaligned / missing operand");
   const TnPlan p = plan_tn(M, N1, N2);
-  if (scratch_bytes < (size_t)p.splits * N1 * N2 * sizeof(float))
-    return fail(FC_ENOMEM, "gemm_tn: scratch needs %zu bytes", (size_t)p.splits * N1 * N2 * sizeof(float));
+  const size_t need = (size_t)p.splits * N1 * (N2 + (colsum ? 4 : 0)) * sizeof(float);
+  if (scratch_bytes < need) return fail(FC_ENOMEM, "gemm_tn: scratch needs %zu bytes", need);
+  if (colsum && ((uintptr_t)colsum & 15)) return fail(FC_EINVAL, "gemm_tn: unaligned column-sum output");
   TnArgs a{};
   a.A = A; a.B = B; a.P = scratch; a.zeros = zeros;
+  a.CS = colsum ? scratch + (size_t)p.splits * N1 * N2 : nullptr;
   a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.rows_per_split = p.rows_per_split; a.a_skip = a_skip;
   const int blocks = p.tiles * p.splits;
   const int rc = p.big ? launch_tn_variant<256, 256, 2, 4>(a, blocks, st) : launch_tn_variant<128, 128, 2, 2>(a, blocks, st);
   if (rc != FC_OK) return rc;
+  if (colsum) {
+    const int rc2 = launch_reduce_partials(a.CS, p.splits, 1, N1, colsum, N1, 1.f, beta, st);
+    if (rc2 != FC_OK) return rc2;
+  }
   return launch_reduce_partials(scratch, p.splits, N1, N2, C, ldc, alpha, beta, st);
-}
-
-size_t colsum_scratch_bytes(int rows, int cols) {
-  const int chunks = std::max(1, std::min(256, (rows + 63) / 64));
-  return (size_t)chunks * cols * sizeof(float);
-}
-
-// out[c] = beta * out[c] + sum_r X[r, c]
-int launch_colsum(const void* X, int kind, long ldx, int rows, int cols, float* out, float beta, float* scratch,
-                  size_t scratch_bytes, hipStream_t st) {
-  if (cols <= 0) return FC_OK;
-  if (rows <= 0) return fail(FC_EINVAL, "colsum: rows=%d", rows);
-  if (cols % 4 || ldx % 4 || (((uintptr_t)X | (uintptr_t)out | (uintptr_t)scratch) & 15))
-    return fail(FC_EINVAL, "colsum: alignment");
-  const int chunks = std::max(1, std::min(256, (rows + 63) / 64));
-  const int rpc = (rows + chunks - 1) / chunks;
-  const int used = (rows + rpc - 1) / rpc;
-  if (scratch_bytes < (size_t)used * cols * sizeof(float)) return fail(FC_ENOMEM, "colsum: scratch too small");
-  const int strips = (cols + 255) / 256;
-  if (kind == PREC_BF16)
-    hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(used * strips), dim3(256), 0, st, (const bf16*)X, ldx, rows, cols, rpc, scratch);
-  else
-    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(used * strips), dim3(256), 0, st, (const float*)X, ldx, rows, cols, rpc, scratch);
-  FC_CHECK_LAUNCH("colsum");
-  return launch_reduce_partials(scratch, used, 1, cols, out, cols, 1.f, beta, st);
 }
 
 }  // namespace fc

@@ -3,7 +3,7 @@
 # Part 2 is tools/profile_round.sh r04 {fp32,fp32x6,bf16,c3}.  Everything lands in gpurun_out/profiles_r04/.
 set -e
 repo=$(pwd); keep=$repo/gpurun_out/profiles_r04; mkdir -p "$keep"
-part=${1:-all}
+part=${1:-all}   # tests | bench | train | all
 if [ "$part" = tests ] || [ "$part" = all ]; then
   timeout -k 10 1500 python3 -m pytest tests -q -m gpu > "$keep/r04_gpu_tests.log" 2>&1 || { tail -30 "$keep/r04_gpu_tests.log"; exit 1; }
   tail -2 "$keep/r04_gpu_tests.log"
@@ -22,4 +22,12 @@ if [ "$part" = bench ] || [ "$part" = all ]; then
   python3 bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline > "$keep/r04_bench_c4_n1.json" 2> "$keep/r04_bench_c4_n1.err"
   echo "c4 done"
   rm -f "$keep"/*.err
+fi
+if [ "$part" = train ] || [ "$part" = all ]; then
+  # the KD training step at one rank's share of configs[4], plain and under the kernel trace (program directly after --)
+  python3 tools/train_bench.py --steps 4 > "$keep/r04_train_step_plain.json" 2> "$keep/train_plain.err"
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d "$keep/prof_train" -o train -- python3 "$repo/tools/train_bench.py" --steps 3 > "$keep/r04_train_step.json" 2> "$keep/train_prof.err")
+  cp "$keep"/prof_train/*/train_kernel_stats.csv "$keep/r04_train_step_kernel_stats.csv" 2>/dev/null || cp "$keep"/prof_train/train_kernel_stats.csv "$keep/r04_train_step_kernel_stats.csv"
+  rm -rf "$keep/prof_train" "$keep"/train_*.err
+  tail -c 400 "$keep/r04_train_step_plain.json"
 fi
