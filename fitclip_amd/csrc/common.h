@@ -48,6 +48,7 @@ enum Epilogue : int {
   EPI_GELU_X3 = 7,    // gemm_split3 only: C(x3 rows [M, 4 N bf16]) = three_planes(quickgelu(acc + bias))   (the next GEMM's A operand)
   EPI_RESID3_F32 = 8, // gemm_split3 only: C(f32) += acc + bias           (three-plane operands in; the residual stream updated in place)
   EPI_RANKS_I32 = 9,  // f32 only (launch_similarity_ranks): C(int32[M]) += #{n : s[m,n] > s[m,t_m] or (== and n < t_m)}, s = alpha acc
+  EPI_GELU_X2 = 10,   // gemm_split2 only: C(x2 rows [M, 2 N fp16]) = two_planes(quickgelu(acc + bias))   (the next GEMM's A operand)
 };
 
 // ---- split-fp32 operands.  An fp32 number is exactly the sum of three bf16 numbers, x = p1 + p2 + p3 (p1 = bf16(x),
@@ -77,6 +78,47 @@ __device__ __forceinline__ void split3(const f32x4& x, bf16x4& p1, bf16x4& p2, b
 }
 #endif
 
+// ---- two-plane fp16 operands ("x2" rows, gemm_split2.h): THREE fp16 products per fp32 product.
+// fp16 carries 11 significand bits, so an fp32 value is h1 + 2^-11 h2 to 22 bits (h1 = fp16(x), h2 = fp16((x - h1) 2^11): the
+// residual is stored SCALED, so it stays in fp16's normal range wherever h1 does - for every |x| in [2^-14, 65504] the pair is
+// exact to 2^-23 |x|, below that to 2^-36 absolute) and a weight is g1 + g2 with g1 = fp16(s w), g2 = fp16(s w - g1), s a power
+// of two per TENSOR chosen at pack time so that max |s w| lies in [2^14, 2^15) (the residual of every weight above 2^-18 of the
+// largest one is a normal fp16 number; smaller ones keep 2^-40 of the largest, absolute).  The product is recovered from
+//     h1 g1 + h1 g2 + h2 (2^-11 g1)            (the dropped h2 g2 term is 2^-22 of the product)
+// - every term exact in the fp16 MFMA's fp32 accumulator; the third weight operand 2^-11 g1 is formed from the g1 FRAGMENT in
+// registers (v_pk_mul_f16, exact for g1 >= 2^-3) - and the accumulator is multiplied by 1 / s in the epilogue (exact).
+// Every 32 columns of a row are one 128-byte line [h1 x32 | h2 x32]: 4 bytes per value, no padding - the bytes of an fp32 row.
+// Values beyond fp16's range (|x| > 65504) cannot be written: the producers set a device-side flag (fc_handle::sat_flag) and
+// the planes hold infinities (the error is loud: NaNs downstream, FC_ERANGE from the next tower call) - never silently wrong.
+constexpr int KIND_X2 = 4;             // element-kind argument of the row kernels: output = x2 rows
+constexpr int X2_GROUP = 32;           // columns per line
+constexpr int X2_GROUP_BYTES = 128;    // bytes per line
+constexpr long x2_row_elems(long K) { return 2 * K; }  // fp16 positions per row
+constexpr float X2_RESID_SCALE = 2048.f;               // 2^11
+#ifdef __HIPCC__
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// activation planes of four values (contraction off: `x - h1` must be the exact fp32 difference of the ROUNDED x)
+__device__ __forceinline__ void split2(const f32x4& x, f16x4& h1, f16x4& h2) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h1[e] = static_cast<_Float16>(x[e]);
+    h2[e] = static_cast<_Float16>((x[e] - static_cast<float>(h1[e])) * X2_RESID_SCALE);
+  }
+}
+// weight planes of four values, xs = s * w: UNSCALED residual
+__device__ __forceinline__ void split2w(const f32x4& xs, f16x4& g1, f16x4& g2) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    g1[e] = static_cast<_Float16>(xs[e]);
+    g2[e] = static_cast<_Float16>(xs[e] - static_cast<float>(g1[e]));
+  }
+}
+#endif
+
 struct GemmArgs {
   const void* A;      // T [M, lda]
   const void* W;      // T [N, ldw]
@@ -98,6 +140,10 @@ struct GemmArgs {
   // column tiles of its row block (grid = row blocks x ceil(column tiles / ctw))
   const int32_t* targets;
   int tgt_off, ctw;
+  // gemm_split2 only: wscale = device pointer to {s, 1 / s} of the weight tensor's x2 image (written by launch_split2_weight);
+  // sat_flag = device int the EPI_GELU_X2 epilogue ORs 1 into when a value exceeds fp16's range (may be null)
+  const float* wscale;
+  int* sat_flag;
 };
 
 // tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = persistent pipelined, 4..7 = pipelined with a forced row cut, 8 = 64x64 on a four-stage ring (gemm.hip)
@@ -108,6 +154,16 @@ int launch_gemm_split3(int epilogue, const GemmArgs& a, hipStream_t stream);
 bool gemm_split3_ok(const GemmArgs& a);
 // x3 image [rows, 4 K bf16] of fp32 rows [rows, K]
 int launch_split3_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, hipStream_t stream);
+// split-fp32 GEMM over two-plane fp16 operands (gemm_split2.h).  a.K counts fp32 columns; a.lda / a.ldw count fp16 positions of
+// the x2 rows (>= 2 K); a.ldc counts floats (EPI_BIAS_F32, EPI_RESID3_F32) or fp16 positions of the x2 output rows
+// (EPI_GELU_X2, >= 2 N); a.wscale is required
+int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream);
+bool gemm_split2_ok(const GemmArgs& a);
+// x2 image [rows, 2 K fp16] of fp32 activation rows [rows, K] (scaled residual plane; sat_flag as in GemmArgs)
+int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int* sat_flag, hipStream_t stream);
+// x2 image of a weight tensor [rows, K] with its per-tensor power-of-two scale: scale2 <- {s, 1 / s} (two device floats), then
+// the planes of s * w (unscaled residual plane).  No host synchronisation.
+int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, hipStream_t stream);
 // the row cut of the fp32 pipelined kernel for an [M, N] output over K columns on the current device: 256-row panels of the head (whole tile
 // rounds) and the height of the tail tiles in 64-row units (0 = no tail)
 void gemm_tail_plan(int M, int N, int K, int* head_panels, int* tail_units);

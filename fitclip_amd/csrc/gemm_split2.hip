@@ -1,0 +1,161 @@
+// Host-side dispatch of the two-plane fp16 split-fp32 GEMM (kernel: gemm_split2.h), the fp32 -> x2 row converter and the weight
+// packer with its per-tensor power-of-two scale (computed on the device: no host synchronisation at pack time).
+#include "gemm_split2.h"
+
+#include <algorithm>
+
+namespace fc {
+
+namespace {
+
+constexpr int kSplit2Lds = 2 * 512 * 128 + 8 * 2048 + 2048;  // two stages, eight patches, two bias slices
+
+template <int EPI, int RW = 2>
+int launch_x2_variant(const GemmArgs& a, hipStream_t stream) {
+  // SPREAD = 2: two LDS-DMA pieces of a K-step in the hand-over, two behind each of the first three MFMA groups of the step before
+  // it is needed (tools/split2_lab)
+  auto kern = gemm_split2_kernel<EPI, 0, 2, RW, 0>;
+  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), kSplit2Lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "gemm_split2: cannot raise dynamic LDS to %d bytes", kSplit2Lds);
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), kSplit2Lds, stream, a);
+  FC_CHECK_LAUNCH("gemm_split2");
+  return FC_OK;
+}
+
+// fp32 rows -> x2 rows: thread per (row, line of 32 columns, quarter): 8 values -> 16 bytes of either plane; the four threads of a
+// line write its 128 bytes
+__global__ void __launch_bounds__(256) split2_rows_kernel(const float* __restrict__ in, long ld_in, char* __restrict__ out,
+                                                          long ld_out_bytes, long rows, int K, const float* __restrict__ scale2,
+                                                          int* sat_flag) {
+  const long per_row = K / 8;  // 8-column pieces
+  const long total = rows * per_row;
+  const bool weight = scale2 != nullptr;
+  const float s = weight ? scale2[0] : 1.f;
+  float amax = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / per_row;
+    const int piece = (int)(i - row * per_row), group = piece >> 2, quarter = piece & 3;
+    const float* src = in + row * ld_in + piece * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src) * s, hi = *reinterpret_cast<const f32x4*>(src + 4) * s;
+    f16x4 a1, a2, b1, b2;
+    if (weight) {
+      split2w(lo, a1, a2);
+      split2w(hi, b1, b2);
+    } else {
+      split2(lo, a1, a2);
+      split2(hi, b1, b2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+    }
+    char* dst = out + row * ld_out_bytes + (long)group * X2_GROUP_BYTES + quarter * 16;
+    auto put = [&](char* p, const f16x4& x, const f16x4& y) {
+      f16x8 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x[e]; v[4 + e] = y[e]; }
+      *reinterpret_cast<f16x8*>(p) = v;
+    };
+    put(dst, a1, b1);
+    put(dst + 64, a2, b2);
+  }
+  if (sat_flag && !(amax <= 65504.f)) atomicOr(sat_flag, 1);
+}
+
+// max |w| over the tensor as the bits of a non-negative float (integer order = float order)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ w, long ld_in, long rows, int K, unsigned* out) {
+  const long per_row = K / 4, total = rows * per_row;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / per_row;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w + row * ld_in + (i - row * per_row) * 4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+// scale2 <- {s, 1 / s}: s = 2^(14 - floor(log2 max)), i.e. max |s w| in [2^14, 2^15); an all-zero (or non-finite) tensor gets 1
+__global__ void scale_from_absmax_kernel(float* scale2) {
+  const float m = __uint_as_float(reinterpret_cast<const unsigned*>(scale2)[0]);
+  float s = 1.f;
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    frexpf(m, &e);                            // m = f 2^e, f in [0.5, 1)  =>  floor(log2 m) = e - 1
+    const int k = max(-100, min(100, 15 - e));
+    s = ldexpf(1.f, k);
+  }
+  scale2[0] = s;
+  scale2[1] = 1.f / s;
+}
+
+}  // namespace
+
+bool gemm_split2_ok(const GemmArgs& a) {
+  return a.M > 0 && a.N > 0 && a.K >= 128 && a.K % 64 == 0 && a.N % 32 == 0 && a.bias != nullptr && a.wscale != nullptr &&
+         ((uintptr_t)a.bias & 15) == 0 && (size_t)256 * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);
+}
+
+int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail(FC_EINVAL, "gemm_split2: empty problem %dx%dx%d", a.M, a.N, a.K);
+  if (a.K % 64 || a.K < 128) return fail(FC_EINVAL, "gemm_split2: K=%d must be a multiple of 64, at least 128", a.K);
+  if (a.N % 32) return fail(FC_EINVAL, "gemm_split2: N=%d must be a multiple of 32", a.N);
+  const long need = x2_row_elems(a.K);
+  if (a.lda < need || a.ldw < need || a.lda % 64 || a.ldw % 64)
+    return fail(FC_EINVAL, "gemm_split2: lda=%d / ldw=%d must cover the %ld fp16 positions of an x2 row in whole 128-byte lines",
+                a.lda, a.ldw, need);
+  if (((uintptr_t)a.A | (uintptr_t)a.W) & 127 || ((uintptr_t)a.C & 15))
+    return fail(FC_EINVAL, "gemm_split2: operands must be 128-byte aligned (x2 rows are made of whole lines)");
+  if (!a.bias || ((uintptr_t)a.bias & 15)) return fail(FC_EINVAL, "gemm_split2: bias missing or unaligned");
+  if (!a.wscale) return fail(FC_EINVAL, "gemm_split2: the weight's scale pair is missing");
+  if ((size_t)256 * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32))
+    return fail(FC_EINVAL, "gemm_split2: the weight (or a 256-row tile of the activations) exceeds the 4 GiB of the kernel's 32-bit row offsets");
+  GemmArgs b = a;
+  if (b.nsplit == 0 && (b.N / 256) % 4 == 0 && b.N / 256 >= 8 && b.N % 256 == 0) b.nsplit = 4;
+  switch (epilogue) {
+    case EPI_BIAS_F32:
+      if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);
+      return launch_x2_variant<EPI_BIAS_F32>(b, stream);
+    case EPI_RESID3_F32:
+      if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);
+      return launch_x2_variant<EPI_RESID3_F32, 2>(b, stream);
+    case EPI_GELU_X2:
+      if (a.ldc % 64 || a.ldc < x2_row_elems(a.N) || ((uintptr_t)a.C & 127))
+        return fail(FC_EINVAL, "gemm_split2: the x2 output needs 128-byte aligned rows of >= 2 N fp16 (ldc=%d)", a.ldc);
+      return launch_x2_variant<EPI_GELU_X2>(b, stream);
+  }
+  return fail(FC_EINVAL, "gemm_split2: epilogue %d", epilogue);
+}
+
+static int check_rows(const char* what, const float* in, long ld_in, void* out, long ld_out, int K) {
+  if (K % X2_GROUP || ld_in % 4 || ld_out % 64 || ld_out < x2_row_elems(K) || ((uintptr_t)in & 15) || ((uintptr_t)out & 127))
+    return fail(FC_EINVAL, "%s: K %% 32, alignment or row stride", what);
+  return FC_OK;
+}
+
+int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int* sat_flag, hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  if (int rc = check_rows("split2_rows", in, ld_in, out, ld_out, K)) return rc;
+  const long total = rows * (K / 8);
+  const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(split2_rows_kernel, dim3(blocks), dim3(256), 0, stream, in, ld_in, static_cast<char*>(out), ld_out * 2, rows, K,
+                     (const float*)nullptr, sat_flag);
+  FC_CHECK_LAUNCH("split2_rows");
+  return FC_OK;
+}
+
+int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, hipStream_t stream) {
+  if (rows <= 0) return FC_OK;
+  if (int rc = check_rows("split2_weight", w, ld_in, out, ld_out, K)) return rc;
+  if (!scale2 || ((uintptr_t)scale2 & 7)) return fail(FC_EINVAL, "split2_weight: scale pair missing or unaligned");
+  if (hipMemsetAsync(scale2, 0, 8, stream) != hipSuccess) return fail(FC_ELAUNCH, "split2_weight: memset");
+  const long total4 = rows * (K / 4);
+  hipLaunchKernelGGL(absmax_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 2048)), dim3(256), 0, stream, w, ld_in, rows, K,
+                     reinterpret_cast<unsigned*>(scale2));
+  hipLaunchKernelGGL(scale_from_absmax_kernel, dim3(1), dim3(1), 0, stream, scale2);
+  const long total = rows * (K / 8);
+  hipLaunchKernelGGL(split2_rows_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, stream, w, ld_in,
+                     static_cast<char*>(out), ld_out * 2, rows, K, (const float*)scale2, (int*)nullptr);
+  FC_CHECK_LAUNCH("split2_weight");
+  return FC_OK;
+}
+
+}  // namespace fc
