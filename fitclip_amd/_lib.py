@@ -16,13 +16,15 @@ LIB_PATH = Path(os.environ.get("FITCLIP_HIP_LIB", _CSRC / "libfitclip_hip.so"))
 
 PREC_F32, PREC_BF16 = 0, 1
 EPI_BIAS_T, EPI_GELU_T, EPI_RESID_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_DGELU_T, EPI_BIAS_F32, EPI_GELU_X3, EPI_RESID3_F32 = range(9)
+EPI_GELU_X2 = 10  # fc_gemm_split2: QuickGELU + x2 rows out
+FC_ERANGE = -5   # split_gemm = 2: a value beyond fp16's range was met
 
 
 class FitclipHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3  # FC_ABI_VERSION of include/fitclip_hip.h
+ABI_VERSION = 4  # FC_ABI_VERSION of include/fitclip_hip.h
 
 
 class fc_config(C.Structure):
@@ -78,6 +80,10 @@ SIGNATURES = {
     "fc_convert": (_i32, [_vp, _vp, _i32, _sz, _vp]),
     "fc_split3": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "fc_gemm_split3": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "fc_split2": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "fc_split2_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "fc_gemm_split2": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "fc_range_status": (_i32, [_vp, _vp, _i32]),
     "fc_set_grad": (_i32, [_vp, C.c_char_p, _vp]),
     "fc_train_weights_bytes": (_sz, [_vp]),
     "fc_train_prepare": (_i32, [_vp, _vp, _sz, _vp]),

@@ -13,9 +13,9 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 REPO = CSRC.parent.parent
 LIB = CSRC / "libfitclip_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm_split3.hip", "attention.hip", "attention_split.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_split3.hip", "gemm_split2.hip", "attention.hip", "attention_split.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
            "train.hip", "bpe.cpp"]
-HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "gemm_split3.h", CSRC / "handle.h", CSRC / "unicode_ranges.inc",
+HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "gemm_split3.h", CSRC / "gemm_split2.h", CSRC / "handle.h", CSRC / "unicode_ranges.inc",
            REPO / "include" / "fitclip_hip.h"]
 ARCH = "gfx950"
 
@@ -25,6 +25,7 @@ ARCH = "gfx950"
 NO_SCRATCH_AUDIT = {
     "gemm.hip": ["gemm_pipelined_kernel", "gemm_kernel"],
     "gemm_split3.hip": ["gemm_split3_kernel"],
+    "gemm_split2.hip": ["gemm_split2_kernel"],
     "attention_split.hip": ["attn_split_kernel"],
     "attention.hip": ["attn_f32_blocks_kernel", "attn_f32_mfma_kernel", "attn_bf16_v2_kernel"],
     "rowops.hip": ["layernorm_kernel", "layernorm_pair_kernel"],

@@ -25,8 +25,10 @@ _PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC
                "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16,
                # fp32 results from the bf16 matrix cores: the block GEMMs of the visual tower over split-fp32 operands
                # (three bf16 numbers per value, six bf16 products per fp32 product: fc_config.split_gemm), all else fp32
-               "fp32x6": _lib.PREC_F32}
-_SPLIT_GEMM = ("fp32x6",)
+               "fp32x6": _lib.PREC_F32,
+               # ... from the fp16 matrix cores: two fp16 planes per value, THREE fp16 products per fp32 product (split_gemm = 2)
+               "fp32x3": _lib.PREC_F32}
+_SPLIT_GEMM = {"fp32x6": 1, "fp32x3": 2}   # precision -> fc_config.split_gemm
 # Opt-in: slices of a big image batch go to this many HIP streams (`CLIP._encode_image_lanes`).  4 gives ~1 % more
 # throughput at 2048 frames, but kernels of different slices then overlap in time, so per-kernel durations (the roofline
 # evidence of bench.py and rocprofv3) stop describing a kernel that owns the chip: off (1) by default.
@@ -142,7 +144,7 @@ class CLIP(nn.Module):
                                  d.context_length, d.vocab_size, d.transformer_width, d.transformer_heads,
                                  d.transformer_layers, _PRECISIONS[self.precision], self.chunk_frames,
                                  self.chunk_texts, self.gemm_tile, int(self.prune_last_block),
-                                 int(self.precision in _SPLIT_GEMM))
+                                 _SPLIT_GEMM.get(self.precision, 0))
             h = _lib._vp()
             _lib.check(lib.fc_create(cfg, h), "fc_create")
             rt.handle, rt.key = h, key
@@ -199,11 +201,21 @@ class CLIP(nn.Module):
                     self._encode_image_lanes(rt, image, out, lanes)
         return out
 
+    def check_range(self, wait: bool = True) -> None:
+        """precision "fp32x3" keeps the block activations as fp16 planes (|x| <= 65504): raises `FitclipHipError` (FC_ERANGE) if a
+        value beyond that was met since the weights were packed.  `wait`: synchronise with the current stream first (call it
+        after the last batch of an evaluation); without it, what the calls completed so far have shown (`encode_image`
+        itself checks that on entry).  A no-op in the other precisions."""
+        rt = self._rt
+        if rt.handle is not None:
+            with torch.cuda.device(self._device()):
+                _lib.check(_lib.load().fc_range_status(rt.handle, _lib.current_stream(), int(wait)), "fc_range_status")
+
     def _chunk_frames(self) -> int:
         if self.chunk_frames > 0:
             return self.chunk_frames
         if self.precision in _SPLIT_GEMM:
-            return 768
+            return 768 if _SPLIT_GEMM[self.precision] == 1 else 1024
         return 2048  # order of the library's pass size (ViT-B/16; csrc/api.hip planned_chunk)
 
     def _encode_image_lanes(self, rt: "_Runtime", image: torch.Tensor, out: torch.Tensor, lanes: int) -> None:

@@ -112,7 +112,7 @@ size_t numel(const std::vector<int64_t>& s) {
 }
 
 // GEMM weights that get a kernel-layout copy
-enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS, PACK_SPLIT3 };
+enum PackMode { PACK_CONVERT, PACK_TRANSPOSE, PACK_PAD_ROWS, PACK_SPLIT3, PACK_SPLIT2 };
 struct PackItem {
   std::string name;
   PackMode mode;
@@ -139,7 +139,7 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
     for (int i = 0; i < h->cfg.vision_layers; ++i) {
       const std::string b = "visual.transformer.resblocks." + std::to_string(i);
       for (const char* n : {".attn.in_proj_weight", ".attn.out_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight"})
-        l.push_back({b + n, PACK_SPLIT3});
+        l.push_back({b + n, h->split2() ? PACK_SPLIT2 : PACK_SPLIT3});
     }
   }
   l.push_back({"visual.proj", PACK_TRANSPOSE});
@@ -149,6 +149,7 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
 size_t packed_item_bytes(const fc_handle* h, const PackItem& e) {
   const auto& shape = h->slots.at(e.name).shape;
   if (e.mode == PACK_SPLIT3) return align_up((size_t)shape[0] * (size_t)x3_row_elems(shape[1]) * 2);
+  if (e.mode == PACK_SPLIT2) return align_up((size_t)shape[0] * (size_t)x2_row_elems(shape[1]) * 2) + 256;  // + the scale pair
   const size_t n = e.mode == PACK_PAD_ROWS ? (size_t)shape[0] * h->patch_kp() : numel(shape);
   return align_up(n * h->esz);
 }
@@ -209,12 +210,13 @@ struct Scratch {
 // workspace carve for `c` items of `tokens` tokens and width `w` (base may be null: sizes only).  `split`: the layout
 // of the split-fp32 visual tower - xn holds x3 rows (8 w bytes of address space), big the fp32 QKV rows or the x3 MLP
 // hidden rows (32 w bytes), d the fp32 deltas; it contains the plain fp32 layout, which small passes fall back to.
-Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, bool split = false) {
+// split = 2 (x2 rows: 4 bytes per value, the fp32 layout's sizes) only adds d.
+Scratch carve(char* base, int c, int tokens, int w, int esz, int min_big_cols, int split = 0) {
   Scratch s{};
   const size_t M = (size_t)c * tokens;
   const size_t big_cols = (size_t)std::max(4 * w, min_big_cols);
-  const size_t xn_row = split ? (size_t)x3_row_elems(w) * 2 : (size_t)w * esz;
-  const size_t big_row = split ? std::max(big_cols * esz, (size_t)x3_row_elems(4 * w) * 2) : big_cols * esz;
+  const size_t xn_row = split == 1 ? (size_t)x3_row_elems(w) * 2 : (size_t)w * esz;
+  const size_t big_row = split == 1 ? std::max(big_cols * esz, (size_t)x3_row_elems(4 * w) * 2) : big_cols * esz;
   const size_t o_x = 0;
   const size_t o_xn = o_x + align_up(M * w * 4);
   const size_t o_big = o_xn + align_up(M * xn_row);
@@ -359,6 +361,57 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
   return launch_layernorm(s.x, pool_step * w, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
 }
 
+// ---- split-fp32 visual tower on TWO fp16 planes (cfg.split_gemm = 2): the sequence of run_blocks_x3 over x2 rows - three fp16
+// products per fp32 product (gemm_split2.h).  Producers: LayerNorm (KIND_X2), the split attention (x2 rows out), c_fc's QuickGELU
+// epilogue (EPI_GELU_X2).  Every writer of x2 rows raises h->sat_flag when a value exceeds fp16's range.
+int gemm_x2(fc_handle* h, int epi, const void* A2, const void* W2, const float* scale2, const float* bias, void* C, int M, int N,
+            int K, int ldc, hipStream_t st) {
+  GemmArgs a{};
+  a.A = A2; a.W = W2; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f; a.wscale = scale2; a.sat_flag = h->sat_flag;
+  a.M = M; a.N = N; a.K = K; a.lda = (int)x2_row_elems(K); a.ldw = a.lda; a.ldc = ldc; a.P = 0;
+  GemmArgs rec = a;  // the profiling record counts the fp16 work: three products per fp32 product (precision code 2 = fp16 pipe)
+  rec.K = 3 * K;
+  ProfScope ps(h, st, 2, epi, 3, rec);
+  return launch_gemm_split2(epi, a, st);
+}
+
+bool x2_pass_ok(int M, int w) { return M > 0 && w >= 128 && w % 64 == 0; }
+
+int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,
+                  const float* fin_b, long pool_step, hipStream_t st, const TowerEntry& entry) {
+  const int M = n_seq * S;
+  const long ld2 = x2_row_elems(w);
+  const size_t nl = t.blocks.size();
+  for (size_t l = 0; l < nl; ++l) {
+    const Block& b = t.blocks[l];
+    if (l == 0) {
+      FC_TRY(launch_layernorm_pair(s.x, entry.cls, entry.pos0, S, entry.pre_w, entry.pre_b, b.ln1_w, b.ln1_b, s.xn,
+                                   KIND_X2, M, w, st));
+    } else {
+      ProfScope ps(h, st, 2, M, w, 1);
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld2, KIND_X2, M, w, st));
+    }
+    FC_TRY(gemm_x2(h, EPI_BIAS_F32, s.xn, b.in_w2, b.in_s2, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
+    {
+      ProfScope ps(h, st, 1, n_seq, heads, S);
+      if (attention_split_supported(S, 0)) {
+        FC_TRY(launch_attention_split(s.big, s.xn, n_seq, S, heads, st, KIND_X2, h->sat_flag));
+      } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
+        FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
+        FC_TRY(launch_split2_rows(s.d, w, s.xn, ld2, M, w, h->sat_flag, st));
+      }
+    }
+    FC_TRY(gemm_x2(h, EPI_RESID3_F32, s.xn, b.out_w2, b.out_s2, b.out_b, s.x, M, w, w, w, st));
+    {
+      ProfScope ps(h, st, 2, M, w, 1);
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, ld2, KIND_X2, M, w, st));
+    }
+    FC_TRY(gemm_x2(h, EPI_GELU_X2, s.xn, b.fc_w2, b.fc_s2, b.fc_b, s.big, M, 4 * w, w, (int)x2_row_elems(4 * w), st));
+    FC_TRY(gemm_x2(h, EPI_RESID3_F32, s.big, b.proj_w2, b.proj_s2, b.proj_b, s.x, M, w, 4 * w, w, st));
+  }
+  return launch_layernorm(s.x, pool_step * w, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
+}
+
 // Items per pass of a tower over `n` items: what bounds a pass is only the workspace it needs (3.6 MB per ViT-B/16 frame in
 // fp32; the GEMMs address their activation rows from 64-bit tile bases).  bf16 and fp32: up to 2048 frames - the measured
 // size (the bench step in ONE pass: bf16 3003 / 3023 / 3066 pairs/s with passes of 512 / 1024 / 2048 frames; fp32 464 -> 474
@@ -371,12 +424,12 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
   const fc_config& c = h->cfg;
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
-  return h->split() ? 768 : 2048;
+  return h->split2() ? 1024 : h->split() ? 768 : 2048;   // (split2: measured in DESIGN.md section 8)
 }
 
 size_t per_item_bytes(const fc_handle* h, int tower) {
   const fc_config& c = h->cfg;
-  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_kp(), h->split()).total;
+  if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_kp(), h->cfg.precision == FC_PREC_F32 ? h->cfg.split_gemm : 0).total;
   return carve(nullptr, 1, c.context_length, c.transformer_width, h->esz, 0).total;
 }
 
@@ -402,8 +455,8 @@ int fc_create(const fc_config* cfg, fc_handle** out) {
                 cfg->struct_size, sizeof(fc_config), FC_ABI_VERSION);
   const fc_config& c = *cfg;
   if (c.precision != FC_PREC_F32 && c.precision != FC_PREC_BF16) return fail(FC_EINVAL, "fc_create: precision");
-  if (c.split_gemm && (c.precision != FC_PREC_F32 || c.vision_width % 256 || c.prune_last_block))
-    return fail(FC_EINVAL, "fc_create: split_gemm needs the fp32 precision, a vision width that is a multiple of 256 and prune_last_block = 0");
+  if (c.split_gemm && (c.precision != FC_PREC_F32 || c.vision_width % 256 || c.prune_last_block || c.split_gemm < 0 || c.split_gemm > 2))
+    return fail(FC_EINVAL, "fc_create: split_gemm (1 or 2) needs the fp32 precision, a vision width that is a multiple of 256 and prune_last_block = 0");
   if (c.vision_width % 64 || c.transformer_width % 64 || c.vision_width <= 0 || c.transformer_width <= 0)
     return fail(FC_EINVAL, "fc_create: widths must be positive multiples of 64 (head dim 64)");
   if (c.transformer_heads * 64 != c.transformer_width)
@@ -426,6 +479,7 @@ int fc_create(const fc_config* cfg, fc_handle** out) {
 void fc_destroy(fc_handle* h) {
   if (!h) return;
   for (auto e : h->ev) (void)hipEventDestroy(e);
+  if (h->sat_host) (void)hipHostFree(h->sat_host);
   delete h;
 }
 
@@ -455,6 +509,7 @@ size_t fc_packed_bytes(const fc_handle* h) {
   if (!h) return 0;
   size_t total = 0;
   for (auto& e : packed_list(h)) total += packed_item_bytes(h, e);
+  if (h->split2()) total += 256;  // the range flag of the x2 writers
   return total;
 }
 
@@ -478,6 +533,15 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       FC_TRY(launch_split3_rows(slot.ptr, (long)slot.shape[1], dst, x3_row_elems(slot.shape[1]), (long)slot.shape[0],
                                 (int)slot.shape[1], stream));
       packed[e.name + "#x3"] = dst;
+      off += packed_item_bytes(h, e);
+      continue;
+    } else if (e.mode == PACK_SPLIT2) {  // [the x2 image | 256 bytes: the {s, 1 / s} pair]
+      const size_t img = packed_item_bytes(h, e) - 256;
+      float* sc = reinterpret_cast<float*>(static_cast<char*>(dst) + img);
+      FC_TRY(launch_split2_weight(slot.ptr, (long)slot.shape[1], dst, x2_row_elems(slot.shape[1]), (long)slot.shape[0],
+                                  (int)slot.shape[1], sc, stream));
+      packed[e.name + "#x2"] = dst;
+      packed[e.name + "#s2"] = sc;
       off += packed_item_bytes(h, e);
       continue;
     } else {
@@ -507,10 +571,34 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       };
       k.in_w3 = x3(".attn.in_proj_weight"); k.out_w3 = x3(".attn.out_proj.weight");
       k.fc_w3 = x3(".mlp.c_fc.weight"); k.proj_w3 = x3(".mlp.c_proj.weight");
+      auto x2 = [&](const char* n, const char* tag) -> const void* {
+        auto it = packed.find(b + n + tag);
+        return it != packed.end() ? it->second : nullptr;
+      };
+      k.in_w2 = x2(".attn.in_proj_weight", "#x2"); k.out_w2 = x2(".attn.out_proj.weight", "#x2");
+      k.fc_w2 = x2(".mlp.c_fc.weight", "#x2"); k.proj_w2 = x2(".mlp.c_proj.weight", "#x2");
+      k.in_s2 = static_cast<const float*>(x2(".attn.in_proj_weight", "#s2")); k.out_s2 = static_cast<const float*>(x2(".attn.out_proj.weight", "#s2"));
+      k.fc_s2 = static_cast<const float*>(x2(".mlp.c_fc.weight", "#s2")); k.proj_s2 = static_cast<const float*>(x2(".mlp.c_proj.weight", "#s2"));
     }
   };
   fill(h->vis, "visual.transformer", h->cfg.vision_layers);
   fill(h->txt, "transformer", h->cfg.transformer_layers);
+  if (h->split2()) {
+    // the range flag (device int behind the packed items, pinned host mirror) starts clear; LayerNorm outputs are bounded by
+    // sqrt(D) max|gamma| + max|beta|: a tower whose LayerNorm weights could leave fp16's range raises the flag here, once
+    h->sat_flag = reinterpret_cast<int*>(static_cast<char*>(arena) + off);
+    off += 256;
+    if (!h->sat_host && hipHostMalloc(reinterpret_cast<void**>(&h->sat_host), 64, hipHostMallocDefault) != hipSuccess)
+      return fail(FC_ENOMEM, "fc_pack_weights: cannot allocate the pinned mirror of the range flag");
+    *h->sat_host = 0;
+    if (hipMemsetAsync(h->sat_flag, 0, 256, stream) != hipSuccess) return fail(FC_ELAUNCH, "fc_pack_weights: memset");
+    for (const Block& k : h->vis.blocks) {
+      FC_TRY(launch_x2_ln_bound(k.ln1_w, k.ln1_b, h->cfg.vision_width, h->sat_flag, stream));
+      FC_TRY(launch_x2_ln_bound(k.ln2_w, k.ln2_b, h->cfg.vision_width, h->sat_flag, stream));
+    }
+  } else {
+    h->sat_flag = nullptr;
+  }
   h->conv_w = gw("visual.conv1.weight");
   h->vproj_t = gw("visual.proj");
   h->tproj_t = gw("text_projection");
@@ -523,7 +611,7 @@ size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n) {
   if (!h || n <= 0 || tower < 0 || tower > 1) return 0;
   const int c = std::min(n, planned_chunk(h, tower, n));
   const fc_config& k = h->cfg;
-  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp(), h->split()).total
+  return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp(), h->cfg.precision == FC_PREC_F32 ? h->cfg.split_gemm : 0).total
                     : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0).total;
 }
 
@@ -532,13 +620,16 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
   if (!h) return fail(FC_EINVAL, "fc_encode_image: null handle");
   if (!h->packed) return fail(FC_ESTATE, "fc_encode_image: call fc_pack_weights first");
   if (n == 0) return FC_OK;
+  if (h->sat_host && *h->sat_host)
+    return fail(FC_ERANGE, "fc_encode_image: an earlier call met an activation (or LayerNorm weights) beyond fp16's range (65504): "
+                           "split_gemm = 2 cannot represent this model's values; its results since then are not valid");
   if (n < 0 || !frames || !out || !ws) return fail(FC_EINVAL, "fc_encode_image: bad argument");
   if (((uintptr_t)frames | (uintptr_t)out | (uintptr_t)ws) & 15) return fail(FC_EINVAL, "fc_encode_image: unaligned pointer");
   const fc_config& c = h->cfg;
   const int vw = c.vision_width, T = h->vtokens(), P = h->patches(), R = c.image_resolution, Kp = h->patch_kp();
   const size_t per = per_item_bytes(h, 0);
   int chunk = std::min(n, planned_chunk(h, 0, n));
-  const bool split = h->split();
+  const int split = h->split() ? h->cfg.split_gemm : 0;
   if (carve(nullptr, chunk, T, vw, h->esz, Kp, split).total > ws_bytes) {  // smaller workspace: as many items as fit
     chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
     while (chunk > 0 && carve(nullptr, chunk, T, vw, h->esz, Kp, split).total > ws_bytes) --chunk;
@@ -565,7 +656,10 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     }
     const TowerEntry entry{h->w("visual.class_embedding"), h->w("visual.positional_embedding"),
                            h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias")};
-    if (split && x3_pass_ok(cn * T, vw)) {
+    if (split == 2 && x2_pass_ok(cn * T, vw)) {
+      FC_TRY(run_blocks_x2(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
+                           h->w("visual.ln_post.bias"), T, st, entry));
+    } else if (split == 1 && x3_pass_ok(cn * T, vw)) {
       FC_TRY(run_blocks_x3(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
                            h->w("visual.ln_post.bias"), T, st, entry));
     } else {  // (split mode: a pass too small for the pipelined GEMM takes the plain fp32 path)
@@ -575,7 +669,21 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }
+  // the range flag follows the call to the host (pinned: no synchronisation; the NEXT call and fc_range_status read it)
+  if (h->sat_flag && hipMemcpyAsync(h->sat_host, h->sat_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+    return fail(FC_ELAUNCH, "fc_encode_image: range flag copy");
   return FC_OK;
+}
+
+int fc_range_status(fc_handle* h, fc_stream st, int32_t wait) {
+  if (!h) return fail(FC_EINVAL, "fc_range_status: null handle");
+  if (!h->sat_flag || !h->sat_host) return FC_OK;   // only split_gemm = 2 writes fp16 planes
+  if (wait) {
+    if (hipMemcpyAsync(h->sat_host, h->sat_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return fail(FC_ELAUNCH, "fc_range_status: flag copy");
+  }
+  return *h->sat_host ? fail(FC_ERANGE, "fc_range_status: a value beyond fp16's range (65504) was met since the weights were packed") : FC_OK;
 }
 
 int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void* ws, size_t ws_bytes, fc_stream st) {
@@ -688,6 +796,10 @@ int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, i
     if (causal) return fail(FC_EINVAL, "fc_attention: split-fp32 attention is not available for causal attention");
     return launch_attention_split(qkv, out, n_seq, S, heads, st);
   }
+  if (precision == ATTN_SPLIT_X2) {  // the same kernel, x2 rows out (two fp16 planes: the operand format of fc_gemm_split2)
+    if (causal) return fail(FC_EINVAL, "fc_attention: split-fp32 attention is not available for causal attention");
+    return launch_attention_split(qkv, out, n_seq, S, heads, st, KIND_X2, nullptr);
+  }
   return launch_attention(precision, qkv, out, n_seq, S, heads, causal, st);
 }
 int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream st) {
@@ -704,6 +816,23 @@ int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, const float
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc;
   if (!A3 || !W3 || !C) return fail(FC_EINVAL, "fc_gemm_split3: null operand");
   return launch_gemm_split3(epilogue, a, st);
+}
+
+int fc_split2(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t* sat_flag, fc_stream st) {
+  if (!in || !out) return fail(FC_EINVAL, "fc_split2: null operand");
+  return launch_split2_rows(in, (long)ld_in, out, (long)ld_out, (long)rows, K, sat_flag, st);
+}
+int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, float* scale2, fc_stream st) {
+  if (!w || !out || !scale2) return fail(FC_EINVAL, "fc_split2_weight: null operand");
+  return launch_split2_weight(w, (long)ld_in, out, (long)ld_out, (long)rows, K, scale2, st);
+}
+int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float* scale2, const float* bias, void* C, int32_t M,
+                   int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, fc_stream st) {
+  GemmArgs a{};
+  a.A = A2; a.W = W2; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f; a.wscale = scale2; a.sat_flag = sat_flag;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc;
+  if (!A2 || !W2 || !C || !scale2) return fail(FC_EINVAL, "fc_gemm_split2: null operand");
+  return launch_gemm_split2(epilogue, a, st);
 }
 
 int fc_profile_enable(fc_handle* h, int32_t max_records) {

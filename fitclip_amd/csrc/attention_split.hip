@@ -95,6 +95,7 @@ struct Ctx {
   long long* stamps;
   int S, heads, D, n_items;
   long ld;
+  int* sat;    // x2 output: device flag for values beyond fp16's range (may be null)
   int tid, lane, wave;
   int stage0;  // first (key, chunk) staging item of this wave (wave-uniform), -1: this wave stages nothing
 
@@ -264,21 +265,39 @@ struct Tile16 {
     }
   }
   // o[n][e] = O(query r, d = 16 n + 4 g + e): the planes of four consecutive columns, 8 bytes per quarter of the line
-  __device__ __forceinline__ void store_out(const Ctx& c, int item) const {
+  // X2: two fp16 planes instead (common.h: a head is two 128-byte lines [h1 x32 | h2 x32]); returns max |value| of this lane
+  template <bool X2>
+  __device__ __forceinline__ float store_out(const Ctx& c, int item) const {
     const int seq = item / c.heads, h = item - seq * c.heads;
     const int query = qtile * 16 + r;
+    float amax = 0.f;
     if (query < c.S && (!F::kNoStore || inv == 123.f)) {
-      char* line = c.out + ((long)seq * c.S + query) * ((long)c.D * 8) + (long)(h * 4) * X3_GROUP_BYTES + g * 8;
+      if constexpr (X2) {
+        char* line = c.out + ((long)seq * c.S + query) * ((long)c.D * 4) + (long)(h * 2) * X2_GROUP_BYTES + g * 8;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        bf16x4 p1, p2, p3;
-        split3x4(o[n] * inv, p1, p2, p3);
-        *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES) = p1;
-        *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES + 32) = p2;
-        *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES + 64) = p3;
-        *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES + 96) = bf16x4{};
+        for (int n = 0; n < 4; ++n) {
+          const f32x4 v = o[n] * inv;
+          amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          f16x4 h1, h2;
+          split2(v, h1, h2);
+          char* dst = line + (n >> 1) * X2_GROUP_BYTES + (n & 1) * 32;
+          *reinterpret_cast<f16x4*>(dst) = h1;
+          *reinterpret_cast<f16x4*>(dst + 64) = h2;
+        }
+      } else {
+        char* line = c.out + ((long)seq * c.S + query) * ((long)c.D * 8) + (long)(h * 4) * X3_GROUP_BYTES + g * 8;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          bf16x4 p1, p2, p3;
+          split3x4(o[n] * inv, p1, p2, p3);
+          *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES) = p1;
+          *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES + 32) = p2;
+          *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES + 64) = p3;
+          *reinterpret_cast<bf16x4*>(line + n * X3_GROUP_BYTES + 96) = bf16x4{};
+        }
       }
     }
+    return amax;
   }
 };
 
@@ -425,11 +444,37 @@ struct Tile32 {
   // v_permlane32_swap per register hands the lower lane columns 0 .. 7 and the upper lane 8 .. 15 of every plane: 16-byte
   // stores, half the store instructions (the address unit works per 128-byte line a store touches - 32 per instruction
   // here - and the 8-byte version kept the waves waiting on it).
-  __device__ __forceinline__ void store_out(const Ctx& x, int item) const {
+  // X2: two fp16 planes (a 32-column half of the head is one line: o[m] IS line m): the same swap hands the lower lane columns
+  // 16 (n & 1) .. + 7 and the upper lane the next eight; returns max |value| of this lane
+  template <bool X2>
+  __device__ __forceinline__ float store_out(const Ctx& x, int item) const {
     const int seq = item / x.heads, h = item - seq * x.heads;
-    if (F::kNoStore && inv != 123.f) return;
-    char* line = x.out + ((long)seq * x.S + min(query, x.S - 1)) * ((long)x.D * 8) + (long)(h * 4) * X3_GROUP_BYTES + hh * 16;
+    if (F::kNoStore && inv != 123.f) return 0.f;
     const bool live = query < x.S;  // (the swaps need every lane)
+    float amax = 0.f;
+    if constexpr (X2) {
+      char* line = x.out + ((long)seq * x.S + min(query, x.S - 1)) * ((long)x.D * 4) + (long)(h * 2) * X2_GROUP_BYTES + hh * 16;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int m = n >> 1, be = 2 * (n & 1);
+        const f32x4 ve = f32x4{o[m][4 * be], o[m][4 * be + 1], o[m][4 * be + 2], o[m][4 * be + 3]} * inv;
+        const f32x4 vo = f32x4{o[m][4 * be + 4], o[m][4 * be + 5], o[m][4 * be + 6], o[m][4 * be + 7]} * inv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) amax = fmaxf(amax, fmaxf(fabsf(ve[q]), fabsf(vo[q])));
+        f16x4 e[2], od[2];
+        split2(ve, e[0], e[1]);
+        split2(vo, od[0], od[1]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const u32x2 ue = __builtin_bit_cast(u32x2, e[p]), uo = __builtin_bit_cast(u32x2, od[p]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(ue[0], uo[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(ue[1], uo[1], false, false);
+          if (live) *reinterpret_cast<u32x4*>(line + m * X2_GROUP_BYTES + (n & 1) * 32 + p * 64) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      }
+      return live ? amax : 0.f;
+    } else {
+    char* line = x.out + ((long)seq * x.S + min(query, x.S - 1)) * ((long)x.D * 8) + (long)(h * 4) * X3_GROUP_BYTES + hh * 16;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int m = n >> 1, be = 2 * (n & 1);
@@ -446,6 +491,8 @@ struct Tile32 {
       }
       if (live) *reinterpret_cast<u32x4*>(line + n * X3_GROUP_BYTES + 96) = u32x4{0u, 0u, 0u, 0u};
     }
+    return 0.f;
+    }
   }
 };
 
@@ -454,11 +501,12 @@ struct Tile32 {
 // softmax; K(i + 1) and Q(i + 1) are requested when the P.V products of item i start, and K(i + 1) replaces K(i) behind
 // them.  Barrier A: K(i) is complete and nobody reads V(i - 1) any more; barrier B: V(i) is complete and nobody reads K(i)
 // any more.
-template <int ABL, class Tile>
+template <int ABL, class Tile, bool X2>
 __device__ __forceinline__ void run_wave(const Ctx& c) {
   using F = Flags<ABL>;
   Tile t;
   t.init(c);
+  float amax = 0.f;
   f32x4 raw[Tile::NITW][2];
   int nstamp = 0;
   auto bar = [&]() {
@@ -496,18 +544,19 @@ __device__ __forceinline__ void run_wave(const Ctx& c) {
     t.pv(c);
     __builtin_amdgcn_sched_barrier(0);
     if (has_next && !F::kNoStage) c.store_kv(0, raw);  // K(i + 1) over K(i): every wave is past barrier B
-    t.store_out(c, item);
+    amax = fmaxf(amax, t.template store_out<X2>(c, item));
     if (!has_next) break;
     item = next;
   }
+  if (X2 && c.sat && !(amax <= 65504.f)) atomicOr(c.sat, 1);
 }
 
-template <int ABL = 0>
+template <int ABL = 0, bool X2 = false>
 __global__ void __launch_bounds__(NT) attn_split_kernel(const float* __restrict__ qkv, char* __restrict__ out, int S, int heads,
-                                                        int n_items, long long* __restrict__ stamps) {
+                                                        int n_items, long long* __restrict__ stamps, int* sat) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ctx c;
-  c.qkv = qkv, c.out = out, c.smem = smem, c.stamps = stamps;
+  c.qkv = qkv, c.out = out, c.smem = smem, c.stamps = stamps, c.sat = sat;
   c.S = S, c.heads = heads, c.D = heads * 64, c.n_items = n_items;
   c.ld = 3L * c.D;
   c.tid = threadIdx.x, c.lane = c.tid & 63;
@@ -528,28 +577,36 @@ __global__ void __launch_bounds__(NT) attn_split_kernel(const float* __restrict_
     }
   }
   if (c.wave + NW < NKT)  // wave-uniform: waves 0 .. 4 carry two query tiles (w, w + 8)
-    run_wave<ABL, Tile32<ABL>>(c);
+    run_wave<ABL, Tile32<ABL>, X2>(c);
   else
-    run_wave<ABL, Tile16<ABL>>(c);
+    run_wave<ABL, Tile16<ABL>, X2>(c);
 }
 
 }  // namespace
 
 bool attention_split_supported(int S, int causal) { return !causal && S > 192 && S <= 208; }
 
-// qkv: f32 [n_seq * S, 3 * heads * 64]; out: x3 rows [n_seq * S, 4 * heads * 64 bf16 positions]
-int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream) {
+// qkv: f32 [n_seq * S, 3 * heads * 64]; out: x3 rows [n_seq * S, 4 * heads * 64 bf16 positions], or - out_kind KIND_X2 - x2 rows
+// [n_seq * S, 2 * heads * 64 fp16 positions] (sat_flag: common.h)
+int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream, int out_kind, int* sat_flag) {
   if (n_seq <= 0) return FC_OK;
   if (!attention_split_supported(S, 0) || heads <= 0) return fail(FC_EINVAL, "attention(split): S=%d heads=%d", S, heads);
+  if (out_kind != KIND_X3 && out_kind != KIND_X2) return fail(FC_EINVAL, "attention(split): output kind %d", out_kind);
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 127)) return fail(FC_EINVAL, "attention(split): unaligned operand");
   const long items = (long)n_seq * heads;
   if (items > 0x7fffffffL) return fail(FC_EINVAL, "attention(split): %ld (sequence, head) pairs", items);
   // (per launch: raise_dynamic_lds memoises per (device, kernel), and the CU count belongs to the current device as well)
-  if (raise_dynamic_lds((const void*)attn_split_kernel<0>, ATTN_SPLIT_LDS) != hipSuccess)  // the six planes: one workgroup per CU
+  const void* kern = out_kind == KIND_X2 ? (const void*)attn_split_kernel<0, true> : (const void*)attn_split_kernel<0, false>;
+  if (raise_dynamic_lds(kern, ATTN_SPLIT_LDS) != hipSuccess)  // the six planes: one workgroup per CU
     return fail(FC_ELAUNCH, "attention(split): cannot raise dynamic LDS");
   const int cus = device_cus();
-  hipLaunchKernelGGL((attn_split_kernel<0>), dim3((unsigned)std::min<long>(items, cus)), dim3(NT), ATTN_SPLIT_LDS, stream,
-                     (const float*)qkv, (char*)out, S, heads, (int)items, (long long*)nullptr);
+  const dim3 grid((unsigned)std::min<long>(items, cus));
+  if (out_kind == KIND_X2)
+    hipLaunchKernelGGL((attn_split_kernel<0, true>), grid, dim3(NT), ATTN_SPLIT_LDS, stream, (const float*)qkv, (char*)out, S, heads,
+                       (int)items, (long long*)nullptr, sat_flag);
+  else
+    hipLaunchKernelGGL((attn_split_kernel<0, false>), grid, dim3(NT), ATTN_SPLIT_LDS, stream, (const float*)qkv, (char*)out, S, heads,
+                       (int)items, (long long*)nullptr, (int*)nullptr);
   FC_CHECK_LAUNCH("attention(split)");
   return FC_OK;
 }

@@ -164,6 +164,8 @@ int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long
 // x2 image of a weight tensor [rows, K] with its per-tensor power-of-two scale: scale2 <- {s, 1 / s} (two device floats), then
 // the planes of s * w (unscaled residual plane).  No host synchronisation.
 int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, hipStream_t stream);
+// raises *sat_flag when LayerNorm outputs under (gamma, beta) could leave fp16's range: sqrt(D) max|gamma| + max|beta| > 65504
+int launch_x2_ln_bound(const float* gamma, const float* beta, int D, int* sat_flag, hipStream_t stream);
 // the row cut of the fp32 pipelined kernel for an [M, N] output over K columns on the current device: 256-row panels of the head (whole tile
 // rounds) and the height of the tail tiles in 64-row units (0 = no tail)
 void gemm_tail_plan(int M, int N, int K, int* head_panels, int* tail_units);
@@ -180,8 +182,11 @@ int launch_attention_x3(const void* qkv, void* out, int n_seq, int S, int heads,
 // split-fp32 attention (attention_split.hip): fp32 qkv in, x3 rows out, both products as six bf16 products on the bf16
 // matrix cores; non-causal, 193..208 tokens (the ViT's 197)
 constexpr int ATTN_SPLIT = 4;  // `precision` argument of fc_attention
+constexpr int ATTN_SPLIT_X2 = 5;  // ... the same kernel with x2 rows out
 bool attention_split_supported(int S, int causal);
-int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream);
+// out_kind: KIND_X3 (x3 rows) or KIND_X2 (x2 rows [n_seq * S, 2 * heads * 64 fp16 positions]; sat_flag as in GemmArgs)
+int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream, int out_kind = 3,
+                           int* sat_flag = nullptr);
 
 // --------------------------------------------------------------------------------------------- row ops
 // y[i] = LN(x[row(i)]) * gamma + beta.  row(i) = gather ? gather[i] : i; x row r at x + r * x_stride.

@@ -12,9 +12,9 @@ constexpr int kSplit2Lds = 2 * 512 * 128 + 8 * 2048 + 2048;  // two stages, eigh
 
 template <int EPI, int RW = 2>
 int launch_x2_variant(const GemmArgs& a, hipStream_t stream) {
-  // SPREAD = 2: two LDS-DMA pieces of a K-step in the hand-over, two behind each of the first three MFMA groups of the step before
-  // it is needed (tools/split2_lab)
-  auto kern = gemm_split2_kernel<EPI, 0, 2, RW, 0>;
+  // SPREAD = 3: the LDS-DMA pieces of a K-step are issued two at a time behind the first four MFMA groups of the step before it is
+  // needed, none in the hand-over (tools/split2_lab: 2 - 4 % over a burst at the hand-over on all four block shapes)
+  auto kern = gemm_split2_kernel<EPI, 0, 3, RW, 0>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), kSplit2Lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split2: cannot raise dynamic LDS to %d bytes", kSplit2Lds);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
@@ -87,7 +87,26 @@ __global__ void scale_from_absmax_kernel(float* scale2) {
   scale2[1] = 1.f / s;
 }
 
+// a LayerNorm output is bounded by sqrt(D) max|gamma| + max|beta| (|x - mean| / std <= sqrt(D - 1)): one wave decides
+__global__ void __launch_bounds__(64) ln_bound_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int D, int* flag) {
+  float mg = 0.f, mb = 0.f;
+  for (int i = threadIdx.x; i < D; i += 64) {
+    mg = fmaxf(mg, fabsf(gamma[i]));
+    mb = fmaxf(mb, fabsf(beta[i]));
+  }
+  mg = wave_max(mg);
+  mb = wave_max(mb);
+  if (threadIdx.x == 0 && !(sqrtf((float)D) * mg + mb <= 65504.f)) atomicOr(flag, 1);
+}
+
 }  // namespace
+
+int launch_x2_ln_bound(const float* gamma, const float* beta, int D, int* sat_flag, hipStream_t stream) {
+  if (!gamma || !beta || !sat_flag || D <= 0) return fail(FC_EINVAL, "x2_ln_bound: bad argument");
+  hipLaunchKernelGGL(ln_bound_kernel, dim3(1), dim3(64), 0, stream, gamma, beta, D, sat_flag);
+  FC_CHECK_LAUNCH("x2_ln_bound");
+  return FC_OK;
+}
 
 bool gemm_split2_ok(const GemmArgs& a) {
   return a.M > 0 && a.N > 0 && a.K >= 128 && a.K % 64 == 0 && a.N % 32 == 0 && a.bias != nullptr && a.wscale != nullptr &&

@@ -20,6 +20,9 @@ struct Block {
   const void *in_w, *out_w, *fc_w, *proj_w;  // element type T of the handle's precision, [N, K]
   // split_gemm: x3 rows [N, 4 K bf16 positions] of the four weights (visual tower only; common.h)
   const void *in_w3 = nullptr, *out_w3 = nullptr, *fc_w3 = nullptr, *proj_w3 = nullptr;
+  // split_gemm 2: x2 rows [N, 2 K fp16 positions] of the four weights and their {s, 1 / s} scale pairs (device floats)
+  const void *in_w2 = nullptr, *out_w2 = nullptr, *fc_w2 = nullptr, *proj_w2 = nullptr;
+  const float *in_s2 = nullptr, *out_s2 = nullptr, *fc_s2 = nullptr, *proj_s2 = nullptr;
   // training: transposed copies [K, N] for the dgrad GEMMs (fc_train_prepare)
   const void *in_wT = nullptr, *out_wT = nullptr, *fc_wT = nullptr, *proj_wT = nullptr;
 };
@@ -40,6 +43,10 @@ struct fc_handle {
   bool packed = false;
   fc::Tower vis, txt;
   const void *conv_w = nullptr, *vproj_t = nullptr, *tproj_t = nullptr;
+  // split_gemm 2: the range flag of the x2 writers - a device int in the packed-weights arena and its pinned host mirror
+  // (copied behind every visual-tower call; allocated by fc_pack_weights, freed by fc_destroy)
+  int* sat_flag = nullptr;
+  int* sat_host = nullptr;
   // training
   bool train_ready = false;
   const float* zeros = nullptr;  // >= 16 KiB of zeros in the training weight arena (null bias / TN tail rows)
@@ -59,7 +66,8 @@ struct fc_handle {
     const int gran = cfg.precision == FC_PREC_BF16 ? 64 : 32;
     return (patch_k() + gran - 1) / gran * gran;
   }
-  bool split() const { return cfg.precision == FC_PREC_F32 && cfg.split_gemm != 0; }
+  bool split() const { return cfg.precision == FC_PREC_F32 && cfg.split_gemm != 0; }   // either split-fp32 mode
+  bool split2() const { return cfg.precision == FC_PREC_F32 && cfg.split_gemm == 2; }  // two fp16 planes, three products
   const float* w(const std::string& n) const { return slots.at(n).ptr; }
   float* grad(const std::string& n) const { return slots.at(n).grad; }
 };

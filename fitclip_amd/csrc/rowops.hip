@@ -66,13 +66,45 @@ __device__ __forceinline__ void store_x3_octet(bf16* row_out, int col, const f32
   *reinterpret_cast<u32x4*>(line) = even;
   *reinterpret_cast<u32x4*>(line + X3_GROUP_BYTES) = odd;
 }
+// Output kind "x2": a row of 2 D fp16 positions, the two-plane image of D fp32 values (common.h: every 32 columns one 128-byte
+// line [h1 x32 | h2 x32], h2 the residual scaled by 2^11).  Written like the x3 rows by a FULL wave: lanes 8k .. 8k + 7 hold the
+// eight adjacent 4-column blocks of ONE line; inside a quad the lanes gather 8 columns of either plane (quad_perm), the two
+// quads exchange what the other one stores (row_shl / row_shr by 4), and lane j of the octet stores chunk j of
+// [h1 cols 0-7 | 8-15 | 16-23 | 24-31 | h2 cols 0-7 | 8-15 | 16-23 | 24-31]: one whole line per store instruction and octet.
+struct x2_t { _Float16 v; };
+__device__ __forceinline__ void store_x2_octet(_Float16* row_out, int col, const f32x4& x, int lane) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f16x4 h1, h2;
+  split2(x, h1, h2);
+  const u32x2 a1 = __builtin_bit_cast(u32x2, h1), a2 = __builtin_bit_cast(u32x2, h2);
+  auto gather = [&](const u32x2& v) {  // lane jq of a quad: columns 8 (jq & 1) .. + 7 of the quad's 16
+    return u32x4{dpp_mov<0x88>(v[0]), dpp_mov<0x88>(v[1]), dpp_mov<0xDD>(v[0]), dpp_mov<0xDD>(v[1])};
+  };
+  auto shift = [&](const u32x4& v, auto CTRL) {
+    constexpr int ctrl = decltype(CTRL)::value;
+    return u32x4{dpp_mov<ctrl>(v[0]), dpp_mov<ctrl>(v[1]), dpp_mov<ctrl>(v[2]), dpp_mov<ctrl>(v[3])};
+  };
+  const u32x4 g1 = gather(a1), g2 = gather(a2);
+  const u32x4 up1 = shift(g1, std::integral_constant<int, 0x104>{});  // row_shl:4 - lanes 2, 3: h1 of the second quad (cols 16-31)
+  const u32x4 dn2 = shift(g2, std::integral_constant<int, 0x114>{});  // row_shr:4 - lanes 4, 5: h2 of the first quad (cols 0-15)
+  const int j = lane & 7;
+  const u32x4 v = j < 2 ? g1 : (j < 4 ? up1 : (j < 6 ? dn2 : g2));
+  char* line = reinterpret_cast<char*>(row_out) + (col / X2_GROUP) * X2_GROUP_BYTES + j * 16;
+  *reinterpret_cast<u32x4*>(line) = v;
+}
 // 4 columns starting at column c of an output row (called by every lane of the wave, lane l on columns .. + 4 l)
 template <typename OutT> __device__ __forceinline__ void put4_at(OutT* row, int c, const f32x4& v) { put4<OutT>(row + c, v); }
 template <> __device__ __forceinline__ void put4_at<x3_t>(x3_t* row, int c, const f32x4& v) {
   store_x3_octet(reinterpret_cast<bf16*>(row), c, v, (int)(threadIdx.x & 63));
 }
+template <> __device__ __forceinline__ void put4_at<x2_t>(x2_t* row, int c, const f32x4& v) {
+  store_x2_octet(reinterpret_cast<_Float16*>(row), c, v, (int)(threadIdx.x & 63));
+}
 template <typename OutT> constexpr int kOutCols = 1;       // output elements per input column
 template <> constexpr int kOutCols<x3_t> = X3_GROUP_BYTES / 2 / X3_GROUP;  // 4 bf16 positions per column
+template <> constexpr int kOutCols<x2_t> = X2_GROUP_BYTES / 2 / X2_GROUP;  // 2 fp16 positions per column
+template <typename OutT> constexpr bool kPlanes = std::is_same_v<OutT, x3_t> || std::is_same_v<OutT, x2_t>;  // plane rows: widths of 256 k only
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // One wave per row, the row lives in registers (D / 64 floats per lane), two-pass mean / centred variance in fp32
@@ -134,7 +166,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
         const int c = V4 * 256 + i * 64 + lane;
-        if constexpr (!std::is_same_v<OutT, x3_t>) put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+        if constexpr (!kPlanes<OutT>) put<OutT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
       }
     }
   }
@@ -210,7 +242,7 @@ __global__ void __launch_bounds__(256) layernorm_pair_kernel(float* __restrict__
         const int c = V4 * 256 + i * 64 + lane;
         s[i] = s[i] * rstd * gamma[c] + beta[c];
         if (pass == 0) xr[c] = s[i];
-        else if constexpr (!std::is_same_v<OutT, x3_t>) put<OutT>(y + (long)row * D + c, s[i]);
+        else if constexpr (!kPlanes<OutT>) put<OutT>(y + (long)row * D + c, s[i]);
       }
     }
   }
@@ -291,7 +323,7 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
         const int c = V4 * 256 + i * 64 + lane;
-        if constexpr (!std::is_same_v<YT, x3_t>) put<YT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
+        if constexpr (!kPlanes<YT>) put<YT>(yr + c, s[i] * rstd * gamma[c] + beta[c]);
       }
     }
   }
@@ -304,7 +336,7 @@ int add_layernorm_dispatch(float* x, long xs, const void* delta, long ds, const 
   const int blocks = min((rows + 3) / 4, kMaxBlocks);
   const T* dl = reinterpret_cast<const T*>(delta);
   YT* yo = reinterpret_cast<YT*>(y);
-  constexpr bool kX3 = std::is_same_v<YT, x3_t>;
+  constexpr bool kX3 = kPlanes<YT>;
 #define FC_ADDLN(W) hipLaunchKernelGGL((add_layernorm_kernel<W, T, YT>), dim3(blocks), dim3(256), 0, st, x, xs, dl, ds, gather, g, b, yo, ys, rows, write_x, delta_compact, x_out)
   switch (D) {
     case 128: if constexpr (kX3) return fail(FC_EINVAL, "add_layernorm: three-plane output needs a width that is a multiple of 256"); else FC_ADDLN(128); break;
@@ -326,7 +358,7 @@ int layernorm_dispatch(const float* x, long xs, const int* gather, const float* 
   OutT* yo = reinterpret_cast<OutT*>(y);
   switch (D) {
     case 128:
-      if constexpr (std::is_same_v<OutT, x3_t>) return fail(FC_EINVAL, "layernorm: three-plane output needs a width that is a multiple of 256");
+      if constexpr (kPlanes<OutT>) return fail(FC_EINVAL, "layernorm: plane-row output needs a width that is a multiple of 256");
       else hipLaunchKernelGGL((layernorm_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows);
       break;
     case 256: hipLaunchKernelGGL((layernorm_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, xs, gather, g, b, yo, ys, rows); break;
@@ -595,6 +627,11 @@ int launch_layernorm(const float* x, long x_stride, const int* gather, const flo
   if ((x_stride % 4) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
     return fail(FC_EINVAL, "layernorm: operands must be 16-byte aligned");
   if (out_kind == KIND_X3) return layernorm_dispatch<x3_t>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
+  if (out_kind == KIND_X2) {
+    if ((y_stride % 64) || y_stride < x2_row_elems(D) || ((uintptr_t)y & 127))
+      return fail(FC_EINVAL, "layernorm: x2 rows need 128-byte aligned rows of >= 2 D fp16 positions");
+    return layernorm_dispatch<x2_t>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
+  }
   return out_kind == 1 ? layernorm_dispatch<bf16>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream)
                        : layernorm_dispatch<float>(x, x_stride, gather, gamma, beta, y, y_stride, rows, D, stream);
 }
@@ -606,7 +643,7 @@ int layernorm_pair_dispatch(float* x, const float* cls, const float* pos0, int t
   OutT* yo = reinterpret_cast<OutT*>(y);
   switch (D) {
     case 128:
-      if constexpr (std::is_same_v<OutT, x3_t>) return fail(FC_EINVAL, "layernorm_pair: three-plane output needs a width that is a multiple of 256");
+      if constexpr (kPlanes<OutT>) return fail(FC_EINVAL, "layernorm_pair: plane-row output needs a width that is a multiple of 256");
       else hipLaunchKernelGGL((layernorm_pair_kernel<128, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows);
       break;
     case 256: hipLaunchKernelGGL((layernorm_pair_kernel<256, OutT>), dim3(blocks), dim3(256), 0, st, x, cls, pos0, tokens, g0, b0, g1, b1, yo, rows); break;
@@ -628,6 +665,10 @@ int launch_layernorm_pair(float* x, const float* cls, const float* pos0, int tok
         (uintptr_t)y) & 15))
     return fail(FC_EINVAL, "layernorm_pair: operands must be 16-byte aligned");
   if (out_kind == KIND_X3) return layernorm_pair_dispatch<x3_t>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
+  if (out_kind == KIND_X2) {
+    if ((uintptr_t)y & 127) return fail(FC_EINVAL, "layernorm_pair: x2 rows must be 128-byte aligned");
+    return layernorm_pair_dispatch<x2_t>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
+  }
   return out_kind == 1 ? layernorm_pair_dispatch<bf16>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream)
                        : layernorm_pair_dispatch<float>(x, cls, pos0, tokens, g0, b0, g1, b1, y, rows, D, stream);
 }
@@ -641,6 +682,13 @@ int launch_add_layernorm(float* x, long x_stride, const void* delta, long d_stri
         (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)delta | (uintptr_t)x_out) & 15))
       return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned");
     return add_layernorm_dispatch<float, x3_t>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows, D,
+                                               write_x, delta_compact, x_out, stream);
+  }
+  if (kind == KIND_X2) {  // delta fp32, y the two-plane fp16 image of the LayerNorm output
+    if ((x_stride % 4) || (d_stride % 4) || (y_stride % 64) || y_stride < x2_row_elems(D) || ((uintptr_t)y & 127) ||
+        (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)delta | (uintptr_t)x_out) & 15))
+      return fail(FC_EINVAL, "add_layernorm: operands must be 16-byte aligned (x2 rows: 128)");
+    return add_layernorm_dispatch<float, x2_t>(x, x_stride, delta, d_stride, gather, gamma, beta, y, y_stride, rows, D,
                                                write_x, delta_compact, x_out, stream);
   }
   const int esz = kind == 1 ? 2 : 4;

@@ -7,12 +7,14 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X3, EPI_PATCH_F32, EPI_RESID3_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
+from ._lib import (EPI_BIAS_F32, EPI_BIAS_T, EPI_GELU_T, EPI_GELU_X2, EPI_GELU_X3, EPI_PATCH_F32, EPI_RESID3_F32, EPI_RESID_F32, EPI_STORE_F32,  # noqa
                    PREC_BF16, PREC_F32)
 
 _KIND = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16}
 KIND_X3 = 3
 ATTN_SPLIT = 4  # fc_attention precision: split-fp32 attention (x3 rows out)
+KIND_X2 = 4     # row kernels: x2 rows out (two fp16 planes, csrc/common.h)
+ATTN_SPLIT_X2 = 5  # fc_attention precision: the split attention with x2 rows out
 # KIND_X3: element-kind argument of the row kernels / attention: x3 rows out (three bf16 planes, csrc/common.h)
 
 
@@ -20,6 +22,11 @@ def _x3_empty(rows: int, cols: int, device) -> torch.Tensor:
     """x3 rows for `cols` fp32 columns: [rows, 4 cols] bf16 positions (every 16 columns one 128-byte line [p1 | p2 | p3 |
     32 bytes no kernel reads or writes]).  Zero-filled so that two images of the same values compare equal."""
     return torch.zeros((rows, 4 * cols), dtype=torch.bfloat16, device=device)
+
+
+def _x2_empty(rows: int, cols: int, device) -> torch.Tensor:
+    """x2 rows for `cols` fp32 columns: [rows, 2 cols] fp16 positions (every 32 columns one 128-byte line [h1 x32 | h2 x32])."""
+    return torch.empty((rows, 2 * cols), dtype=torch.float16, device=device)
 
 
 def _dev(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -83,43 +90,51 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
     elif rows is None:
         rows = x.numel() // row_stride
     x3 = out_dtype == "x3"  # three-plane rows (split3 layout)
-    y = _x3_empty(rows, D, x.device) if x3 else torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    x2 = out_dtype == "x2"  # two fp16 planes (split2 layout)
+    y = (_x3_empty(rows, D, x.device) if x3 else _x2_empty(rows, D, x.device) if x2
+         else torch.empty((rows, D), dtype=out_dtype, device=x.device))
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().fc_layernorm(x.data_ptr(), row_stride, _ptr(gather), gamma.data_ptr(), beta.data_ptr(),
-                                            y.data_ptr(), y.shape[1], KIND_X3 if x3 else _KIND[out_dtype], rows, D,
+                                            y.data_ptr(), y.shape[1], KIND_X3 if x3 else KIND_X2 if x2 else _KIND[out_dtype], rows, D,
                                             _lib.current_stream()), "fc_layernorm")
     return y
 
 
 def add_layernorm(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                  write_x: bool = True, three_plane: bool = False) -> torch.Tensor:
+                  write_x: bool = True, three_plane: bool = False, two_plane: bool = False) -> torch.Tensor:
     """x += delta (in place, if write_x); returns LayerNorm(x + delta) in delta's dtype, or (`three_plane`, fp32 delta) as
-    x3 rows [rows, 4 D] (split3 layout)."""
-    _dev(x, "x", torch.float32), _dev(delta, "delta", torch.float32 if three_plane else None), _dev(gamma, "gamma", torch.float32)
+    x3 rows [rows, 4 D] (split3 layout), or (`two_plane`) as x2 rows [rows, 2 D] (split2 layout)."""
+    planes = three_plane or two_plane
+    _dev(x, "x", torch.float32), _dev(delta, "delta", torch.float32 if planes else None), _dev(gamma, "gamma", torch.float32)
     rows, D = x.shape
-    y = _x3_empty(rows, D, x.device) if three_plane else torch.empty((rows, D), dtype=delta.dtype, device=x.device)
+    y = (_x3_empty(rows, D, x.device) if three_plane else _x2_empty(rows, D, x.device) if two_plane
+         else torch.empty((rows, D), dtype=delta.dtype, device=x.device))
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().fc_add_layernorm(x.data_ptr(), D, delta.data_ptr(), D, None, gamma.data_ptr(),
                                                 beta.data_ptr(), y.data_ptr(), y.shape[1],
-                                                KIND_X3 if three_plane else _KIND[delta.dtype], rows, D,
+                                                KIND_X3 if three_plane else KIND_X2 if two_plane else _KIND[delta.dtype], rows, D,
                                                 int(write_x), _lib.current_stream()), "fc_add_layernorm")
     return y
 
 
 def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False,
-              three_plane: bool = False, split: bool = False) -> torch.Tensor:
+              three_plane: bool = False, split: bool = False, two_plane: bool = False) -> torch.Tensor:
     """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]; `three_plane`
     (float32 qkv, non-causal, 113..224 tokens): x3 rows [.., 4 * heads * 64] of the fp32 result; `split` (193..208 tokens):
-    x3 rows too, both products as six bf16 products per fp32 product on the bf16 matrix cores (fp32 accuracy)."""
-    three_plane = three_plane or split
-    _dev(qkv, "qkv", torch.float32 if three_plane else None)
+    x3 rows too, both products as six bf16 products per fp32 product on the bf16 matrix cores (fp32 accuracy); `split` with
+    `two_plane`: the same kernel, x2 rows [.., 2 * heads * 64] out (split2 layout)."""
+    if two_plane and not split:
+        raise ValueError("x2 rows come from the split attention only (split=True)")
+    three_plane = (three_plane or split) and not two_plane
+    _dev(qkv, "qkv", torch.float32 if (three_plane or two_plane) else None)
     D = heads * 64
     if qkv.shape != (n_seq * seq_len, 3 * D):
         raise ValueError(f"qkv shape {tuple(qkv.shape)} != {(n_seq * seq_len, 3 * D)}")
-    out = (_x3_empty(n_seq * seq_len, D, qkv.device) if three_plane
+    out = (_x3_empty(n_seq * seq_len, D, qkv.device) if three_plane else _x2_empty(n_seq * seq_len, D, qkv.device) if two_plane
            else torch.empty((n_seq * seq_len, D), dtype=qkv.dtype, device=qkv.device))
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().fc_attention(ATTN_SPLIT if split else KIND_X3 if three_plane else _KIND[qkv.dtype], qkv.data_ptr(), out.data_ptr(),
+        _lib.check(_lib.load().fc_attention(ATTN_SPLIT_X2 if two_plane else ATTN_SPLIT if split else KIND_X3 if three_plane else _KIND[qkv.dtype],
+                                            qkv.data_ptr(), out.data_ptr(),
                                             n_seq, seq_len, heads, int(causal), _lib.current_stream()), "fc_attention")
     return out
 
@@ -168,6 +183,71 @@ def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, epilogue
         _lib.check(_lib.load().fc_gemm_split3(epilogue, a3.data_ptr(), w3.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K,
                                               a3.stride(0), w3.stride(0), out.stride(0), _lib.current_stream()),
                    "fc_gemm_split3")
+    return out
+
+
+def split2(x: torch.Tensor, flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x2 rows [rows, 2 K fp16 positions] of fp32 ACTIVATION rows [rows, K] (fc_split2): h1 = fp16(x), h2 = fp16((x - h1) 2^11);
+    every 32 columns one 128-byte line [h1 x32 | h2 x32].  `flag` (int32 [1], optional): 1 is ORed in when |x| > 65504."""
+    _dev(x, "x", torch.float32)
+    if x.dim() != 2 or x.shape[1] % 32:
+        raise ValueError("split2 needs [rows, K] with K a multiple of 32")
+    if flag is not None:
+        _dev(flag, "flag", torch.int32)
+    out = _x2_empty(x.shape[0], x.shape[1], x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().fc_split2(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                                         _ptr(flag), _lib.current_stream()), "fc_split2")
+    return out
+
+
+def split2_weight(w: torch.Tensor):
+    """(x2 rows [N, 2 K], scale pair float32 [2] = {s, 1 / s}) of a WEIGHT [N, K] (fc_split2_weight): s the power of two that
+    puts max |s w| into [2^14, 2^15); g1 = fp16(s w), g2 = fp16(s w - g1).  Operand pair of `gemm_split2`."""
+    _dev(w, "w", torch.float32)
+    if w.dim() != 2 or w.shape[1] % 32:
+        raise ValueError("split2_weight needs [N, K] with K a multiple of 32")
+    out = _x2_empty(w.shape[0], w.shape[1], w.device)
+    scale = torch.empty(2, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().fc_split2_weight(w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), w.shape[0], w.shape[1],
+                                                scale.data_ptr(), _lib.current_stream()), "fc_split2_weight")
+    return out, scale
+
+
+def x2_planes(x2: torch.Tensor):
+    """The two planes [rows, K] (float16) of x2 rows [rows, 2 K] (a view per plane; test / lab helper).  Activations:
+    x = h1 + h2 / 2048; weights: s w = g1 + g2."""
+    v = x2.view(x2.shape[0], -1, 2, 32)
+    return tuple(v[:, :, i].reshape(x2.shape[0], -1) for i in range(2))
+
+
+def gemm_split2(a2: torch.Tensor, w2: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, epilogue: int = EPI_BIAS_F32,
+                out: Optional[torch.Tensor] = None, flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue(A @ W^T) for x2 operands a2 [M, 2 K] (`split2`, LayerNorm / attention x2 outputs, a previous EPI_GELU_X2 GEMM) and
+    (w2 [N, 2 K], scale) from `split2_weight`: three fp16 MFMA products per fp32 product, fp32 accumulate (fc_gemm_split2).
+    EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X2 -> x2 rows [M, 2 N] of QuickGELU(A @ W^T + bias); EPI_RESID3_F32: `out`
+    (float32 [M, N]) += A @ W^T + bias, in place."""
+    _dev(a2, "a2", torch.float16), _dev(w2, "w2", torch.float16), _dev(bias, "bias", torch.float32), _dev(scale, "scale", torch.float32)
+    if a2.dim() != 2 or w2.dim() != 2 or a2.shape[1] != w2.shape[1] or a2.shape[1] % 64:
+        raise ValueError(f"x2 operands need matching [rows, 2 K] shapes, got {tuple(a2.shape)} and {tuple(w2.shape)}")
+    M, N, K = a2.shape[0], w2.shape[0], a2.shape[1] // 2
+    if epilogue == EPI_GELU_X2:
+        out = _x2_empty(M, N, a2.device)
+    elif epilogue == EPI_BIAS_F32:
+        out = torch.empty((M, N), dtype=torch.float32, device=a2.device)
+    elif epilogue == EPI_RESID3_F32:
+        if out is None or out.shape != (M, N):
+            raise ValueError("the residual epilogue accumulates into `out` [M, N]")
+        _dev(out, "out", torch.float32)
+    else:
+        raise ValueError("gemm_split2 has the epilogues EPI_BIAS_F32, EPI_GELU_X2 and EPI_RESID3_F32")
+    if flag is not None:
+        _dev(flag, "flag", torch.int32)
+    with torch.cuda.device(a2.device):
+        _lib.check(_lib.load().fc_gemm_split2(epilogue, a2.data_ptr(), w2.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                              M, N, K, a2.stride(0), w2.stride(0), out.stride(0), _ptr(flag), _lib.current_stream()),
+                   "fc_gemm_split2")
     return out
 
 

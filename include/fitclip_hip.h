@@ -40,7 +40,8 @@ typedef enum {
   FC_EINVAL = -1,  /* bad argument (shape, alignment, unknown name) */
   FC_ELAUNCH = -2, /* HIP launch / runtime error */
   FC_ENOMEM = -3,  /* workspace or arena too small */
-  FC_ESTATE = -4   /* call order (weights missing / not packed) */
+  FC_ESTATE = -4,  /* call order (weights missing / not packed) */
+  FC_ERANGE = -5   /* split_gemm = 2: an activation (or LayerNorm weights) beyond fp16's range was met - results not valid */
 } fc_status;
 
 typedef enum {
@@ -49,7 +50,7 @@ typedef enum {
 } fc_precision;
 
 /* ABI revision of this header: bumped whenever a struct or a signature changes; the tail of fc_version() names it. */
-#define FC_ABI_VERSION 3
+#define FC_ABI_VERSION 4
 
 /* Architecture: the keys of config/encoder/clip_from_scratch_vit_b_16.yaml:5-16 (heads = width / 64 as in
  * clip.model.CLIP).  Head dimension must be 64.
@@ -80,7 +81,12 @@ typedef struct {
                                  fc_split3), every product as six bf16 products accumulated in fp32 (fc_gemm_split3) -
                                  at fp32 accuracy and ~1.6x the fp32-MFMA rate; LayerNorm, attention, residual stream,
                                  patch embedding, the text tower and passes too small for that GEMM stay on the plain
-                                 fp32 path.  0 (default): fp32-input MFMA everywhere */
+                                 fp32 path.  2: the same GEMMs on the fp16 matrix cores over TWO-plane operands ("x2" rows,
+                                 fc_split2: x = h1 + 2^-11 h2 in fp16) with THREE products per fp32 product
+                                 (fc_gemm_split2) - fp32 accuracy at ~2.7x the fp32-MFMA rate.  fp16 planes hold
+                                 |x| <= 65504: a value beyond that raises a device-side flag and the NEXT fc_encode_image
+                                 (and fc_range_status) returns FC_ERANGE - never silently wrong.
+                                 0 (default): fp32-input MFMA everywhere */
 } fc_config;
 #define FC_CONFIG_INIT {(int32_t)sizeof(fc_config)}
 
@@ -116,6 +122,11 @@ FC_API int fc_encode_image(fc_handle* h, const float* frames, int32_t n_frames, 
                     size_t workspace_bytes, fc_stream stream);
 FC_API int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n_texts, float* out, void* workspace,
                    size_t workspace_bytes, fc_stream stream);
+/* split_gemm = 2 only (FC_OK otherwise): FC_ERANGE when a writer of fp16 planes met a value beyond 65504 since
+ * fc_pack_weights (activations of the visual tower's blocks; or LayerNorm weights whose outputs could exceed it).  wait != 0:
+ * first waits for the work queued on `stream` (one host synchronisation - call it after the last batch of an evaluation);
+ * wait == 0: what the flag copies of the calls completed so far have shown (fc_encode_image itself checks this on entry). */
+FC_API int fc_range_status(fc_handle* h, fc_stream stream, int32_t wait);
 
 /* Eval transform on the device (clip_video_text_encoder.py:125-133): frames dev uint8 [n, H, W, 3]
  * -> out dev f32 [n, 3, R, R] = normalise(center_crop(bicubic_resize(frames / 255, shorter side R), R)).  mean3 / std3
@@ -181,6 +192,7 @@ FC_API int fc_layernorm(const float* x, int64_t x_stride, const int32_t* gather,
 /* v = x[r] + delta[r]; if write_x: x[r] = v; y[i] = LayerNorm(v) * gamma + beta, r = gather ? gather[i] : i.  The
  * residual update of a pre-LN block (slip.py:382-385) folded into the LayerNorm that follows it.  delta and y have
  * element kind `kind`; kind 3: delta fp32, y x3 rows (fc_split3 layout, y_stride >= 4 D bf16 positions, 128-byte aligned;
+ * fc_layernorm too); kind 4: delta fp32, y x2 rows (fc_split2 layout, y_stride >= 2 D fp16 positions, 128-byte aligned;
  * fc_layernorm too). */
 FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64_t d_stride, const int32_t* gather,
                      const float* gamma, const float* beta, void* y, int64_t y_stride, int32_t kind, int32_t rows,
@@ -191,7 +203,7 @@ FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64
  * precision 3: fp32 qkv in, x3 rows out (fc_split3 layout; non-causal, 113..224 tokens), the fp32 kernel's values.
  * precision 4: the same operands and layout, both products formed as six bf16 products per fp32 product on the bf16 matrix
  * cores (fc_gemm_split3's arithmetic; fp32 accuracy, not the fp32 kernel's bits; non-causal, 193..208 tokens): the attention
- * of the split_gemm mode. */
+ * of the split_gemm mode.  precision 5: as 4, x2 rows out (fc_split2 layout): the attention of split_gemm = 2. */
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);
@@ -207,6 +219,24 @@ FC_API int fc_split3(const float* in, int64_t ld_in, void* out, int64_t ld_out, 
  * x = x + proj(..) of slip.py:382-385 in the projection's epilogue).  K % 32 == 0, K >= 64, N % 32 == 0; operands below 4 GiB. */
 FC_API int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, const float* bias, void* C, int32_t M, int32_t N,
                    int32_t K, int32_t lda, int32_t ldw, int32_t ldc, fc_stream stream);
+
+/* Two-plane fp16 operands ("x2" rows, split_gemm = 2): fp32 rows [rows, K] -> h1 = fp16(x), h2 = fp16((x - h1) 2^11), i.e.
+ * x = h1 + 2^-11 h2 to 2^-23 |x| for |x| in [2^-14, 65504] (2^-36 absolute below).  Every 32 columns become one 128-byte line
+ * [h1 x32 | h2 x32]; a row is 2 K fp16 positions = the bytes of the fp32 row (ld_out counts fp16 positions, a multiple of 64;
+ * `out` 128-byte aligned).  K % 32 == 0.  sat_flag (may be null): device int, 1 is ORed in when |x| > 65504 was met. */
+FC_API int fc_split2(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t* sat_flag,
+              fc_stream stream);
+/* ... of a WEIGHT tensor [rows, K]: scale2 (two device floats) <- {s, 1 / s} with s the power of two that puts max |s w| into
+ * [2^14, 2^15), then g1 = fp16(s w), g2 = fp16(s w - g1) (unscaled residual) in the same line layout.  No host synchronisation. */
+FC_API int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, float* scale2,
+                     fc_stream stream);
+/* C = epilogue((A . W^T) / s) over x2 operands A2 [M, K] (fc_split2, LayerNorm kind 4, attention precision 5, epilogue 10) and
+ * W2 [N, K] (fc_split2_weight, with its scale2): the three fp16 products h1 g1 + h1 g2 + h2 (2^-11 g1) of every fp32 product
+ * on v_mfma_f32_32x32x16_f16, accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-22 per product.
+ * epilogue 6: C fp32 [M, N] = acc + bias; 8: C fp32 += acc + bias in place; 10: C x2 rows [M, 2 N fp16] =
+ * planes(QuickGELU(acc + bias)) (sat_flag as in fc_split2).  K % 64 == 0, K >= 128, N % 32 == 0; operands below 4 GiB. */
+FC_API int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float* scale2, const float* bias, void* C,
+                   int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, fc_stream stream);
 
 /* ---- training: the KD fine-tuning step of the student -------------------------------------------
  * Replaces autograd + torch.optim.AdamW for `TeacherStudentLightningModule.training_step / training_step_end /

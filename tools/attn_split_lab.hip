@@ -56,7 +56,7 @@ template <int ABL>
 void run_split(const float* qkv, char* out, int n_seq, int S, int heads, int reps, const char* what) {
   auto kern = attn_split_kernel<ABL>;
   HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_SPLIT_LDS));
-  const float ms = time_it([&] { hipLaunchKernelGGL(kern, dim3(std::min(n_seq * heads, 256)), dim3(512), ATTN_SPLIT_LDS, 0, qkv, out, S, heads, n_seq * heads, (long long*)nullptr); }, reps);
+  const float ms = time_it([&] { hipLaunchKernelGGL(kern, dim3(std::min(n_seq * heads, 256)), dim3(512), ATTN_SPLIT_LDS, 0, qkv, out, S, heads, n_seq * heads, (long long*)nullptr, (int*)nullptr); }, reps);
   printf("split ABL %2d  %-44s %8.3f ms\n", ABL, what, ms);
 }
 
