@@ -47,9 +47,10 @@ The same JSON line carries
     device path over the whole batch, and on the CPU sample the device path ("gpu"), the oracle ("ref") and "delta".
   * "cpu_baseline": the CPU oracle (oracle/clip_oracle.py, kind "port") timed on this host's cores over a bounded
     sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample.
-  * `fp32_split_mode`: the same step with `precision="fp32x6"` - the visual tower's block GEMMs on the bf16 matrix
-    cores over split-fp32 operands (fc_config.split_gemm) - with its parity against the fp32 path and the oracle.
-    A labelled secondary mode like `bf16_mode`; never `value`.
+  * `fp32_split_mode`: the same step with `precision="fp32x3"` - the visual tower's block GEMMs on the fp16 matrix cores
+    over two-plane split-fp32 operands, three fp16 products per fp32 product (fc_config.split_gemm = 2) - with its parity
+    against the fp32 path and the oracle.  A labelled secondary mode like `bf16_mode`; never `value`.  `--split6` adds
+    `fp32_split6_mode` (precision "fp32x6": three bf16 planes, six bf16 products - the split mode of rounds 2-4).
   * `kd_training_step` (N = 1 only, after the timed region): the distillation training step at one
     rank's share of BASELINE configs[4]; never part of `value`.
 """
@@ -74,7 +75,7 @@ sys.path.insert(0, REPO)
 
 GF_PER_FRAME = 35.127e9   # BASELINE.md section 3 (GEMM + attention MACs x 2)
 GF_PER_TEXT = 5.960e9
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
 EPI_BIAS, EPI_GELU = 0, 1
 EPI_NAMES = {0: "bias", 1: "bias_quickgelu", 2: "bias_residual", 3: "patch_embed", 4: "store_f32"}
 EPI_RESID = 2
@@ -204,7 +205,7 @@ def load_traffic(precision, shape, epilogue):
     from fitclip_amd.build import source_fingerprint
     fp = source_fingerprint()
     seen = []
-    for name in (f"traffic_r04_{precision}.json", f"traffic_r04_{precision}_c3.json", f"traffic_r03_{precision}.json",
+    for name in (f"traffic_r05_{precision}.json", f"traffic_r04_{precision}.json", f"traffic_r04_{precision}_c3.json", f"traffic_r03_{precision}.json",
                  f"traffic_r02_{precision}.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.exists(path):
@@ -416,21 +417,38 @@ def run_mode(precision, sd, video, text, args, shards, device, backend, full_det
     return out, (ev, et, all_ranks)
 
 
-def run_split_mode(sd, video, text, args, shards, device, backend):
-    """Secondary leg `fp32_split_mode` (precision "fp32x6"): the same step with the visual tower's block GEMMs on the bf16
-    matrix cores over split-fp32 operands (three bf16 planes per value, six bf16 products per fp32 product formed from
-    registers, fp32 accumulate: csrc/gemm_split3.h) - fp32 accuracy from the pipe that is 16x faster than the fp32-input one.  Timed like the headline; the
-    per-kernel figures come from one instrumented extra step."""
+SPLIT_MODES = {
+    # precision -> (products per fp32 product, profiling precision code of its GEMM records, their epilogues, pipe, kernel, dtype)
+    "fp32x3": (3, 2, {6: "bias_f32_out", 10: "bias_quickgelu_x2_out", 8: "bias_residual_f32_out"}, "fp16",
+               "gemm_split2_kernel<256x256><two fp16 planes per operand, three MFMA products per fp32 product, {epi}>",
+               "fp32 values as two fp16 numbers (x = h1 + 2^-11 h2; weights with a power-of-two scale per tensor); three fp16 MFMA "
+               "products per fp32 product, fp32 accumulate (the visual tower's block GEMMs); the attention products as six bf16 "
+               "products; LayerNorm, softmax arithmetic, residual stream, patch embedding and the text tower in plain fp32"),
+    "fp32x6": (6, 1, {6: "bias_f32_out", 7: "bias_quickgelu_x3_out", 8: "bias_residual_f32_out"}, "bf16",
+               "gemm_split3_kernel<256x256><three bf16 planes per operand, six MFMA products per fp32 product, {epi}>",
+               "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate (the visual "
+               "tower's block GEMMs and attention products); LayerNorm, softmax arithmetic, residual stream, patch "
+               "embedding and the text tower in plain fp32"),
+}
+
+
+def run_split_mode(sd, video, text, args, shards, device, backend, precision="fp32x3"):
+    """Secondary legs `fp32_split_mode` (precision "fp32x3": the visual tower's block GEMMs on the fp16 matrix cores over two-plane
+    operands, THREE fp16 products per fp32 product formed from registers, csrc/gemm_split2.h) and `fp32_split6_mode` (`--split6`;
+    precision "fp32x6": three bf16 planes, six bf16 products, csrc/gemm_split3.h) - fp32 accuracy from the pipes that are 16x
+    faster than the fp32-input one.  Timed like the headline; the per-kernel figures come from one instrumented extra step."""
     from fitclip_amd.clip_model import build_clip
     from fitclip_amd.encoder import ClipVideoTextEncoder
 
-    enc = ClipVideoTextEncoder(build_clip(sd, precision="fp32x6", device=device, chunk_frames=args.split_chunk_frames),
+    nprod, prec_code, epi_names, pipe, kernel_fmt, dtype = SPLIT_MODES[precision]
+    enc = ClipVideoTextEncoder(build_clip(sd, precision=precision, device=device, chunk_frames=args.split_chunk_frames),
                                num_frames=args.frames)
     n_local = shards.n_local
     step = make_step(enc, video, text, shards)
     for _ in range(args.warmup):
         step()
     elapsed, (ev, et, all_ranks) = timed_steps(step, args.steps, device, backend)
+    enc.model.check_range()   # (fp32x3: FC_ERANGE if an activation left fp16's range; a no-op otherwise)
     enc.model.profile(16384)
     enc.model.profile_reset()
     overlap, enc.overlap_text = enc.overlap_text, False
@@ -441,35 +459,33 @@ def run_split_mode(sd, video, text, args, shards, device, backend):
     enc.overlap_text = overlap
     records = enc.model.profile_records()
     enc.model.profile(0)
-    six = [r for r in records if r["kind"] == 0 and r["epilogue"] in (6, 7, 8) and r["ms"] > 0]
+    six = [r for r in records if r["kind"] == 0 and r["precision"] == prec_code and r["epilogue"] in epi_names and r["ms"] > 0]
     by = defaultdict(lambda: [0.0, 0])
     for r in six:
         by[(r["epilogue"], r["N"], r["K"], r["M"])][0] += r["ms"]
         by[(r["epilogue"], r["N"], r["K"], r["M"])][1] += 1
     (epi, N, K6, M), (ms, cnt) = max(by.items(), key=lambda kv: kv[1][0])
-    bf16_flops = 2.0 * M * N * K6  # executed on the bf16 pipe: six products per fp32 product
-    epi_name = {6: "bias_f32_out", 7: "bias_quickgelu_x3_out", 8: "bias_residual_f32_out"}[epi]
-    traffic, traffic_note = load_traffic("fp32x6", (M, N, K6), epi_name)
+    pipe_flops = 2.0 * M * N * K6  # executed on the matrix pipe: `nprod` products per fp32 product
+    epi_name = epi_names[epi]
+    traffic, traffic_note = load_traffic(precision, (M, N, K6), epi_name)
     six_ms = sum(r["ms"] for r in six)
     six_flops = sum(2.0 * r["M"] * r["N"] * r["K"] for r in six)
     step_flops = n_local * (args.frames * GF_PER_FRAME + GF_PER_TEXT)
     other = aggregate(records)[1]
     return {
+        "precision": precision,
         "value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate (the visual "
-                 "tower's block GEMMs and attention products); LayerNorm, softmax arithmetic, residual stream, patch "
-                 "embedding and the text tower in plain fp32",
-        "roofline": {"bound": "mfma", "kernel": f"gemm_split3_kernel<256x256><three bf16 planes per operand, six MFMA products "
-                                                f"per fp32 product, {epi_name}> M={M} N={N} K={K6 // 6} (x 6 products)",
-                     "achieved": round(bf16_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                     "frac": round(bf16_flops * cnt / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),
-                     "fp32_equivalent_tflops": round(bf16_flops / 6 * cnt / (ms * 1e-3) / 1e12, 1),
+        "dtype": dtype,
+        "roofline": {"bound": "mfma", "kernel": kernel_fmt.format(epi=epi_name) + f" M={M} N={N} K={K6 // nprod} (x {nprod} products)",
+                     "achieved": round(pipe_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS[pipe], "unit": "TFLOP/s",
+                     "frac": round(pipe_flops * cnt / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[pipe], 4),
+                     "fp32_equivalent_tflops": round(pipe_flops / nprod * cnt / (ms * 1e-3) / 1e12, 1),
                      "launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "traffic": traffic, "traffic_note": traffic_note,
                      "timing": "hipEvent pairs in the instrumented extra step"},
-        "six_plane_gemms": {"achieved": round(six_flops / (six_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s of bf16 MFMA",
-                            "frac": round(six_flops / (six_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4),
-                            "fp32_equivalent_tflops": round(six_flops / 6 / (six_ms * 1e-3) / 1e12, 1),
-                            "share_of_step_time": round(six_ms / (split_elapsed * 1e3), 4)},
+        "plane_gemms": {"achieved": round(six_flops / (six_ms * 1e-3) / 1e12, 1), "unit": f"TFLOP/s of {pipe} MFMA",
+                        "frac": round(six_flops / (six_ms * 1e-3) / 1e12 / PEAK_TFLOPS[pipe], 4),
+                        "fp32_equivalent_tflops": round(six_flops / nprod / (six_ms * 1e-3) / 1e12, 1),
+                        "share_of_step_time": round(six_ms / (split_elapsed * 1e3), 4)},
         "whole_path_fp32_equivalent_tflops": round(step_flops * args.steps / elapsed / 1e12, 2),
         "time_split": {**{k: {"share_of_step_time": round(v[0] / (split_elapsed * 1e3), 4), "launches": v[1],
                               "avg_launch_ms": round(v[0] / max(1, v[1]), 4)} for k, v in other.items()},
@@ -745,6 +761,7 @@ def main() -> None:
                     help="headline precision; fp32 = the reference's (default).  bf16 here is for kernel work only")
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the secondary bf16-operand run")
     ap.add_argument("--no-split-mode", action="store_true", help="skip the secondary split-fp32 run (fp32_split_mode)")
+    ap.add_argument("--split6", action="store_true", help="also run the six-product split mode of rounds 2-4 (fp32_split6_mode, precision fp32x6)")
     ap.add_argument("--clips", type=int, default=256, help="c2: clips (= captions) per GPU per step")
     ap.add_argument("--frames", type=int, default=None, help="frames per clip (default 8; c4: 16)")
     ap.add_argument("--chunk-frames", type=int, default=0)
@@ -959,24 +976,28 @@ def main() -> None:
 
     ev6 = et6 = None
 
-    def split_leg():
+    def split_leg(precision="fp32x3", key="fp32_split_mode"):
         torch.cuda.empty_cache()
-        s6, (v6, t6, ranks6) = run_split_mode(sd, video, text, args, shards, device, args.backend)
+        s6, (v6, t6, ranks6) = run_split_mode(sd, video, text, args, shards, device, args.backend, precision)
         m6 = D.metrics_from_ranks(ranks6.cpu().numpy())
         s6["retrieval"] = m6
         s6["recall_delta_vs_fp32_path"] = {k: round(m6[k] - metrics[k], 6) for k in ("r1", "r5", "r10", "mr")}
         s6["ranks_identical_to_fp32_path"] = bool(torch.equal(ranks6, all_ranks))
         s6["embedding_max_abs_vs_fp32_path"] = {"video": float((v6 - ev).abs().max()), "text": float((t6 - et).abs().max())}
         s6["speedup_vs_headline"] = round(s6["value"] / result["value"], 3)
-        s6["note"] = ("secondary mode, never `value`: products are formed on the bf16 pipe, but from exact three-term splits "
-                      "of the fp32 operands - see parity on the CPU sample (`on_sample`) at the fp32 tolerances")
-        result["fp32_split_mode"] = s6
+        s6["note"] = ("secondary mode, never `value`: products are formed on the %s pipe, from splits of the fp32 operands that are "
+                      "exact to %s - see parity on the CPU sample (`on_sample`) at the fp32 tolerances"
+                      % (("fp16", "2^-22 per product (two fp16 planes, three products)") if precision == "fp32x3"
+                         else ("bf16", "2^-26 per product (three bf16 planes, six products)")))
+        result[key] = s6
         return v6, t6
 
     if secondary and not args.no_split_mode:
         got = legs.run("fp32_split_mode", split_leg)
         if got is not None:
             ev6, et6 = got
+        if args.split6:
+            legs.run("fp32_split6_mode", lambda: split_leg("fp32x6", "fp32_split6_mode"))
 
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_train_leg and n_local >= 4:
         got = legs.run("kd_training_step", lambda: training_leg({**sd, **unplanted}, video, ids, args, dims, device))

@@ -38,6 +38,9 @@ DEFAULTS: Dict[str, Any] = {
     "command": "evaluate", "encoder": "clip_vit_b_16", "data": "synthetic", "seed": 42, "n_clips": 64,
     "num_frames": 4, "eval_batch_size": 32, "init_temperature": 0.015, "precision": None, "weight_for_2": None,
     "gpus": 1, "backend": "nccl", "bpe_path": None,
+    # evaluate on several ranks: loss/val over the per-step GATHERED batch, as the reference logs it (text_video_retrieval.py:
+    # 44-58), instead of every rank's own batches (retrieval.TextVideoRetrievalModule); the retrieval metrics are the same
+    "gather_batches": False,
     # command=train (config/teacher_student_trainer.yaml + config/data/mixed_batch_*.yaml): per-rank batch composition
     "steps": 10, "n_labeled": 8, "n_unlabeled": 8, "lr": 3e-6, "fit_temperature": False, "output_path": "predictions.pt",
     "repeat_batch": False,  # train: every step sees the first batch again (overfitting smoke test)
@@ -112,11 +115,20 @@ def evaluate(cfg: Mapping[str, Any]) -> Dict[str, float]:
         raise SystemExit("only data=synthetic is available offline (no datasets in this environment)")
     n = cfg["n_clips"]
     start, end = D.shard_bounds(n, world, rank)
-    module = TextVideoRetrievalModule(encoder, init_temperature=cfg["init_temperature"], n_total=n)
+    gather = bool(cfg.get("gather_batches"))
+    module = TextVideoRetrievalModule(encoder, init_temperature=cfg["init_temperature"], n_total=n, gather_batches=gather)
     bs = cfg["eval_batch_size"]
+    # gather_batches (the reference's per-batch gathered loss/val): every rank runs the step count of the largest shard - a
+    # shard that ends early feeds empty batches, which only take part in the gather (the reference's sampler pads instead)
+    steps = -(-max(D.shard_counts(n, world)) // bs) if gather else -(-(end - start) // bs)
     with torch.inference_mode():
-        for s in range(start, end, bs):
+        for i in range(steps):
+            s = min(end, start + i * bs)
             e = min(end, s + bs)
+            if e == s:   # (gather_batches only: this shard has ended, the step still takes part in the gather)
+                empty = torch.empty((0, dims.embed_dim), dtype=torch.float32, device=device)
+                module.validation_step_end((empty, empty))
+                continue
             batch = {"video": torch.from_numpy(synth.make_video(e - s, cfg["num_frames"], dims, cfg["seed"], s)).to(device),
                      "text": {"input_ids": torch.from_numpy(synth.make_text(e - s, dims, cfg["seed"], s)).to(device)},
                      "video_id": [f"clip{i}" for i in range(s, e)]}

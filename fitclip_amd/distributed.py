@@ -69,14 +69,28 @@ def all_gather_rows(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
     return torch.cat([gathered[r * biggest: r * biggest + c] for r, c in enumerate(counts)])
 
 
+def all_gather_counts(n_local: int, device) -> List[int]:
+    """Row counts of every rank's local batch (one tiny collective + a host read: only the per-batch gather of
+    `TextVideoRetrievalModule(gather_batches=True)` needs it - shards and training batches know their sizes)."""
+    rank, world_size = world()
+    if not collectives_active():
+        return [n_local]
+    on_host = dist.get_backend() == "gloo"
+    mine = torch.tensor([n_local], dtype=torch.int64, device="cpu" if on_host else device)
+    out = torch.empty(world_size, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(c) for c in out.tolist()]
+
+
 def all_gather_many(tensors: Sequence[torch.Tensor], counts: Sequence[int]) -> List[torch.Tensor]:
     """`all_gather_rows` of several [n_local, d_i] tensors in ONE collective (they are packed side by side into one
     [n_local, sum d_i] buffer): the (student video, student text, teacher video, teacher text) tuple the reference's
     wrapper walks tensor by tensor (tensor_utils.py:48-66, teacher_student.py:143)."""
     if not collectives_active():
         return list(tensors)
-    widths = [t.shape[1] for t in tensors]
-    gathered = all_gather_rows(torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1), counts)
+    widths = [int(np.prod(t.shape[1:])) for t in tensors]
+    # (an EMPTY local batch - a shard that ended early in a per-batch gather - still takes part with its [0, width] rows)
+    gathered = all_gather_rows(torch.cat([t.reshape(t.shape[0], w) for t, w in zip(tensors, widths)], dim=1), counts)
     return [g.contiguous() for g in gathered.split(widths, dim=1)]
 
 

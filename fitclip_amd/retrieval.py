@@ -56,10 +56,20 @@ class VideoTextModule:
 
 
 class TextVideoRetrievalModule(VideoTextModule):
+    """`gather_batches` chooses what `loss/val` means on more than one rank (the retrieval metrics do not depend on it):
+      * False (default): every rank computes the NCE of ITS eval batches (B rows) and the epoch mean is all-reduced - the one
+        exchange step the path needs is the embedding all-gather at the epoch's end;
+      * True: the reference's semantics (text_video_retrieval.py:44-58): every step all-gathers the batch's embeddings over
+        the ranks first and the NCE is taken over the world x B gathered rows (a larger contrastive batch: a larger loss).
+        One collective per eval batch; every rank must run the same number of steps (the reference's DDP sampler pads the
+        shards to that; `python -m fitclip_amd gather_batches=true` feeds empty batches where a shard ends early).
+    On ONE rank the two are the same number."""
+
     def __init__(self, encoder: VideoTextEncoder, init_temperature: float = 0.05, min_temperature: float = 0.001,
-                 n_total: Optional[int] = None) -> None:
+                 n_total: Optional[int] = None, gather_batches: bool = False) -> None:
         super().__init__(encoder, init_temperature, min_temperature)
         self.n_total = n_total
+        self.gather_batches = bool(gather_batches)
         self._outputs: List[TYPE_OUTPUT] = []
         self._losses: List[Tuple[torch.Tensor, int]] = []
 
@@ -71,16 +81,28 @@ class TextVideoRetrievalModule(VideoTextModule):
         reference gathers the batch across DDP ranks first; with exact clip shards every rank logs its own batches
         and the epoch-level mean is all-reduced instead."""
         encoded_video, encoded_text = output
-        loss = ops.nce_loss(self.step_scores(encoded_video, encoded_text))
-        # (the loss stays on the device until the epoch ends, as Lightning's `self.log` keeps it: a `float()` here would drain
-        # the stream after every 32-clip batch)
-        self._losses.append((loss, len(encoded_video)))
-        self._outputs.append(output)
+        if self.gather_batches and D.collectives_active():
+            # `all_gather(self, output)` of the reference: the rows of every rank's batch, in rank order (ragged last batches:
+            # the sizes are exchanged first - this is the per-batch collective the default mode exists to avoid)
+            counts = D.all_gather_counts(len(encoded_video), encoded_video.device)
+            if sum(counts):
+                gathered_video, gathered_text = D.all_gather_many((encoded_video, encoded_text), counts)
+                self._losses.append((ops.nce_loss(self.step_scores(gathered_video, gathered_text)), sum(counts)))
+        elif len(encoded_video):
+            loss = ops.nce_loss(self.step_scores(encoded_video, encoded_text))
+            # (the loss stays on the device until the epoch ends, as Lightning's `self.log` keeps it: a `float()` here would
+            # drain the stream after every 32-clip batch)
+            self._losses.append((loss, len(encoded_video)))
+        if len(encoded_video):
+            self._outputs.append(output)   # the LOCAL rows: the epoch-end scoring gathers once
         return output
 
     def validation_epoch_end(self) -> Dict[str, float]:
         """cat all batches, scores = T @ V^T, target = arange, R@1/5/10 + median rank
         (text_video_retrieval.py:67-83); the scores only ever exist tile by tile inside `fc_similarity_ranks`."""
+        model = getattr(self.encoder, "model", None)
+        if hasattr(model, "check_range"):
+            model.check_range()   # precision fp32x3: an activation beyond fp16's range since the weights were packed is an error
         encoded_videos = torch.cat([o[0] for o in self._outputs])
         encoded_texts = torch.cat([o[1] for o in self._outputs])
         rank, world_size = D.world()

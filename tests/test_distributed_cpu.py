@@ -128,6 +128,78 @@ def test_teacher_student_step_end_gathers_across_ranks(tmp_path):
         assert np.load(out + f".{rank}.npy").tolist() == pytest.approx(want, rel=1e-5)
 
 
+class _ToyEncoder:
+    """Encoder stand-in for the CPU workers: the "embeddings" of a batch are the planted rows themselves."""
+
+    def __call__(self, video, text):
+        return video, text
+
+
+def _loss_val_worker(rank: int, world: int, port: int, sizes, gather: bool, out_path: str) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fitclip_amd.retrieval as R
+
+        class _Ops(_OracleOps):
+            similarity_ranks = staticmethod(lambda t, v, off: O.ranks_of_target(O.retrieval_scores(t, v), torch.arange(t.shape[0]) + off))
+
+        R.ops = _Ops()
+        n = sum(sum(per_rank) for per_rank in sizes)
+        v, t = _planted(n, seed=3)
+        # rank r owns a contiguous shard, cut into the batch sizes given for it (an entry 0 = a step with an empty local batch)
+        start = sum(sum(sizes[r]) for r in range(rank))
+        module = R.TextVideoRetrievalModule(_ToyEncoder(), init_temperature=0.015, n_total=n, gather_batches=gather)
+        for b in sizes[rank]:
+            module.validation_step_end(module.validation_step({"video": v[start:start + b].contiguous(), "text": t[start:start + b].contiguous()}))
+            start += b
+        metrics = module.validation_epoch_end()
+        np.save(out_path + f".{rank}.npy", np.array([metrics[k] for k in ("loss/val", "r1", "r5", "r10", "mr")]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [((8, 8), (8, 8)), ((8, 8, 1), (8, 8, 0)), ((8, 5), (8, 4))])
+def test_loss_val_semantics_on_two_ranks(tmp_path, sizes):
+    """What `loss/val` means at N > 1.  gather_batches=True is the REFERENCE's number (text_video_retrieval.py:44-58: every
+    step all-gathers the batch over the ranks, NCE over the world x B rows, logged with batch_size = the gathered size);
+    the default logs every rank's own batches and all-reduces the weighted mean.  Both give the same retrieval metrics; the
+    losses differ (a larger contrastive batch has a larger NCE), and each must equal the oracle's value for ITS definition.
+    Ragged cases: a last batch only one rank has (the other feeds an empty one), last batches of different sizes."""
+    n = sum(sum(r) for r in sizes)
+    v, t = _planted(n, seed=3)
+    ref = O.retrieval_metrics(O.retrieval_scores(t, v))
+    offs = [0, sum(sizes[0])]
+    # the reference's number: step i gathers rank 0's batch i and rank 1's batch i, in rank order
+    num = den = 0.0
+    pos = list(offs)
+    for b0, b1 in zip(*sizes):
+        rows = list(range(pos[0], pos[0] + b0)) + list(range(pos[1], pos[1] + b1))
+        pos[0] += b0
+        pos[1] += b1
+        num += float(O.nce_loss(O.step_scores(v[rows], t[rows], 0.015))) * len(rows)
+        den += len(rows)
+    want_gathered = num / den
+    # the default's number: every local batch on its own, weighted by its size
+    num = den = 0.0
+    for r in range(2):
+        p = offs[r]
+        for b in sizes[r]:
+            if b:
+                num += float(O.nce_loss(O.step_scores(v[p:p + b], t[p:p + b], 0.015))) * b
+                den += b
+            p += b
+    want_local = num / den
+    assert want_gathered > want_local + 1e-3   # the two definitions are different numbers on this task
+    for gather, want in ((True, want_gathered), (False, want_local)):
+        out = str(tmp_path / f"lv{int(gather)}")
+        mp.spawn(_loss_val_worker, args=(2, _free_port(), sizes, gather, out), nprocs=2, join=True)
+        for rank in range(2):
+            got = np.load(out + f".{rank}.npy")
+            assert got[0] == pytest.approx(want, rel=1e-5), (gather, rank)
+            assert got[1:].tolist() == pytest.approx([ref["r1"], ref["r5"], ref["r10"], ref["mr"]])
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a torch.distributed.run environment starts two rank processes by itself
     (fresh children, 127.0.0.1 rendezvous) and rank 0 prints ONE JSON line.  `--dry-run`: no GPU work on this box."""

@@ -256,7 +256,7 @@ def test_evaluate_driver_reproduces_config1_golden(golden_dir, capsys):
     assert abs(out["loss/val"] - float(g["loss_val"])) < 2e-3
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x6", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x6", "fp32x3", "bf16"])
 @pytest.mark.parametrize("clips,frames,n_text", [(256, 8, 256), (1024, 16, 1024)])
 def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_text, precision):
     """BASELINE configs[1] (256 clips x 8 frames + 256 texts) and one rank's shard of configs[3] (1024 clips x 16
@@ -598,6 +598,47 @@ def test_two_rank_evaluate_equals_single_rank():
     for k in ("r1", "r5", "r10", "mr"):
         assert one[k] == two[k], (k, one, two)
     assert abs(one["loss/val"] - two["loss/val"]) < 1e-5
+
+
+def test_two_rank_evaluate_with_gathered_batches_logs_the_references_loss():
+    """`gather_batches=true`: loss/val as the reference logs it on several ranks - the NCE of the per-step GATHERED batch
+    (text_video_retrieval.py:44-58).  Two gloo ranks on one GPU, 21 clips = shards of 11 + 10 in batches of 4 (a ragged last
+    step): step i scores rank 0's batch i together with rank 1's batch i.  Expected value: the same row sets scored in this
+    process through the same operators; the retrieval metrics do not depend on the option."""
+    import math
+    common = ["-m", "fitclip_amd", "command=evaluate", "encoder=clip_vit_b_16", "n_clips=21", "num_frames=1",
+              "precision=fp32", "eval_batch_size=4", "gpus=2", "backend=gloo"]
+    plain = _run(common)
+    gathered = _run(common + ["gather_batches=true"])
+    for k in ("r1", "r5", "r10", "mr"):
+        assert plain[k] == gathered[k], (k, plain, gathered)
+    d = synth.VIT_B_16
+    from fitclip_amd.__main__ import instantiate, load_encoder_config, parse_overrides
+    cfg = parse_overrides(["encoder=clip_vit_b_16", "precision=fp32"])
+    enc = instantiate(load_encoder_config("clip_vit_b_16", cfg, DEV)).to(DEV)
+    video = torch.from_numpy(synth.make_video(21, 1, d, seed=42)).to(DEV)
+    ids = torch.from_numpy(synth.make_text(21, d, seed=42)).to(DEV)
+    ev, et = enc(video=video, text={"input_ids": ids})
+    scale = 1.0 / 0.015
+
+    def nce(rows):
+        idx = torch.tensor(rows, device=DEV)
+        return float(ops.nce_loss(ops.similarity(ev[idx].contiguous(), et[idx].contiguous(), alpha=scale))) * len(rows), len(rows)
+
+    shard = [(0, 11), (11, 21)]
+    num = den = 0.0
+    for i in range(3):
+        rows = [c for s, e in shard for c in range(min(e, s + 4 * i), min(e, s + 4 * i + 4))]
+        a, b = nce(rows)
+        num, den = num + a, den + b
+    assert gathered["loss/val"] == pytest.approx(num / den, abs=2e-5)
+    num = den = 0.0
+    for s, e in shard:
+        for lo in range(s, e, 4):
+            a, b = nce(list(range(lo, min(e, lo + 4))))
+            num, den = num + a, den + b
+    assert plain["loss/val"] == pytest.approx(num / den, abs=2e-5)
+    assert gathered["loss/val"] > plain["loss/val"] + 1e-3 and math.isfinite(gathered["loss/val"])
 
 
 def test_bench_two_ranks_on_one_gpu_rehearsal():

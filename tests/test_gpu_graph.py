@@ -48,7 +48,7 @@ def _capture_and_replay(enc, video, ids, replays=3):
     return eager
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x6", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x6", "fp32x3", "bf16"])
 def test_reference_shaped_call_replays_bitwise_from_a_hipgraph(vitb16_state_dict, precision):
     d = synth.VIT_B_16
     enc = ClipVideoTextEncoder(build_clip(vitb16_state_dict, precision=precision, device=DEV), num_frames=4)
