@@ -1,6 +1,7 @@
 """Builds fitclip_amd/csrc/libfitclip_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m fitclip_amd.build [--force] [--save-temps]
+    python -m fitclip_amd.build --host-asan      # CPU sanitizer target: csrc/bpe.cpp under ASan + UBSan (tests/test_sanitize.py)
 """
 from __future__ import annotations
 
@@ -147,14 +148,18 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src.replace(".hip", ".o").replace(".cpp", ".o"))
-        if force or _stale(obj, [CSRC / src, *HEADERS]):
+        audited = src in ASYNC_LOAD_AUDIT or src in NO_SCRATCH_AUDIT
+        asm = objdir / (src.replace(".hip", "") + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+        # an audited source is compiled with -save-temps and its ISA checked on EVERY build: an up-to-date object whose .s file is
+        # missing or older than the source (built before the source joined an audit table) is recompiled, never linked unaudited
+        if force or _stale(obj, [CSRC / src, *HEADERS]) or (audited and _stale(asm, [CSRC / src, *HEADERS])):
             cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
-            if save_temps or src in ASYNC_LOAD_AUDIT or src in NO_SCRATCH_AUDIT:
+            if save_temps or audited:
                 cmd += ["-save-temps=obj"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True, cwd=str(objdir))
-            asm = objdir / (src.replace(".hip", "") + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+        if audited:
             try:
                 for kernel in ASYNC_LOAD_AUDIT.get(src, []):
                     audit_async_loads(asm, kernel)
@@ -177,5 +182,26 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
     return lib_path
 
 
+HOST_ASAN = CSRC / "build" / "bpe_asan"
+
+
+def build_host_asan(verbose: bool = True) -> Path:
+    """CPU sanitizer target (never the GPU build): the host-only part of the library - csrc/bpe.cpp, which parses external
+    gzip files and arbitrary UTF-8 - with g++ -fsanitize=address,undefined and the driver tests/host/bpe_sanitize_driver.cpp.
+    tests/test_sanitize.py runs the tokenizer fixtures and a seeded corpus of hostile inputs through it."""
+    driver = REPO / "tests" / "host" / "bpe_sanitize_driver.cpp"
+    HOST_ASAN.parent.mkdir(exist_ok=True)
+    if _stale(HOST_ASAN, [CSRC / "bpe.cpp", CSRC / "unicode_ranges.inc", driver, REPO / "include" / "fitclip_hip.h"]):
+        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+               "-fno-sanitize-recover=all", "-Wall", str(CSRC / "bpe.cpp"), str(driver), "-o", str(HOST_ASAN), "-lz"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return HOST_ASAN
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, lab="--lab" in sys.argv))
+    if "--host-asan" in sys.argv:
+        print(build_host_asan())
+    else:
+        print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, lab="--lab" in sys.argv))

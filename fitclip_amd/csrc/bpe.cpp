@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -209,14 +210,28 @@ extern "C" {
 
 int fc_bpe_create(const char* merges_gz_path, int32_t context_length, fc_bpe** out) {
   if (!merges_gz_path || !out || context_length < 2) return fail(FC_EINVAL, "fc_bpe_create: bad argument");
+  {
+    // zlib reads a file WITHOUT the gzip header transparently (as plain text): any garbage would load as a 514-entry vocabulary.
+    // The merges file is a gzip member (bpe_simple_vocab_16e6.txt.gz): anything else is refused here.
+    FILE* raw = fopen(merges_gz_path, "rb");
+    if (!raw) return fail(FC_EINVAL, "fc_bpe_create: cannot open %s", merges_gz_path);
+    unsigned char magic[2] = {0, 0};
+    const size_t n = fread(magic, 1, 2, raw);
+    fclose(raw);
+    if (n != 2 || magic[0] != 0x1f || magic[1] != 0x8b)
+      return fail(FC_EINVAL, "fc_bpe_create: %s is not a gzip file (no 1f 8b magic)", merges_gz_path);
+  }
   gzFile f = gzopen(merges_gz_path, "rb");
   if (!f) return fail(FC_EINVAL, "fc_bpe_create: cannot open %s", merges_gz_path);
   std::string text;
   char buf[1 << 16];
   int got;
   while ((got = gzread(f, buf, sizeof(buf))) > 0) text.append(buf, got);
+  int zerr = Z_OK;
+  (void)gzerror(f, &zerr);
   gzclose(f);
-  if (got < 0) return fail(FC_EINVAL, "fc_bpe_create: %s is not a readable gzip file", merges_gz_path);
+  if (got < 0 || (zerr != Z_OK && zerr != Z_STREAM_END))   // (a truncated or corrupt member: never a silently shorter merge list)
+    return fail(FC_EINVAL, "fc_bpe_create: %s is not a readable gzip file (zlib error %d)", merges_gz_path, zerr);
 
   auto* t = new fc_bpe();
   t->context_length = context_length;

@@ -323,6 +323,15 @@ int launch_gemm_tn(const float* A, const float* B, int M, int N1, int N2, int ld
   const TnPlan p = plan_tn(M, N1, N2);
   const size_t need = (size_t)p.splits * N1 * (N2 + (colsum ? 4 : 0)) * sizeof(float);
   if (scratch_bytes < need) return fail(FC_ENOMEM, "gemm_tn: scratch needs %zu bytes", need);
+  // the kernel walks A and B through running 32-bit byte offsets from a split's first row (a_skip rows included): a split whose
+  // rows span 4 GiB would wrap silently (few splits over very many rows: N1 = N2 = 4096 is one split per tile)
+  {
+    const size_t span_rows = (size_t)p.rows_per_split + 2 * TN_BK;
+    const size_t a_rows = a_skip > 0 ? span_rows + span_rows / (size_t)a_skip + 2 : span_rows;
+    if (a_rows * (size_t)lda * sizeof(float) >= (1ull << 32) || span_rows * (size_t)ldb * sizeof(float) >= (1ull << 32))
+      return fail(FC_EINVAL, "gemm_tn: %d rows per split x lda=%d / ldb=%d exceed the 4 GiB of the kernel's 32-bit row offsets "
+                             "(M=%d in %d split(s)): split the rows over several calls with beta = 1", p.rows_per_split, lda, ldb, M, p.splits);
+  }
   if (colsum && ((uintptr_t)colsum & 15)) return fail(FC_EINVAL, "gemm_tn: unaligned column-sum output");
   TnArgs a{};
   a.A = A; a.B = B; a.P = scratch; a.zeros = zeros;

@@ -59,7 +59,7 @@ def main():
     # visual-tower launches of the pipelined GEMMs run for > 80 us at chunk >= 256 frames; the text tower's for < 60 us
     # (fp32: visual >= 900 us, text <= 350 us)
     # (fp32 bench step: one pass of 2048 frames; the shortest visual launch, out_proj, runs 3.5 ms - or 0.6 ms in the short
-    # pass of a step that is split, e.g. 1663 + 385 under FITCLIP_MAX_PASS_FRAMES=1774)
+    # pass of a step that is split, e.g. 768 + 768 + 512 with `chunk_frames=768`)
     # (the reference-shaped call of bench.py --config c3, 128 frames: out_proj runs 0.26 ms, the text tower's launches < 0.1 ms)
     cut = (500.0 if chunk >= 512 else 150.0) if fp32 else 70.0
     cut_small = 100.0 if fp32 else 40.0
