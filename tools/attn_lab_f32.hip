@@ -2,7 +2,6 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fitclip_amd/csrc -I include tools/attn_lab_f32.hip -o tools/bin/attn_lab_f32
 //   tools/bin/attn_lab_f32 [n_seq=1024] [reps=10]
 #include "../fitclip_amd/csrc/attention.hip"
-#include "attn_persist_lab.h"
 
 #include <cstdarg>
 #include <algorithm>
@@ -61,41 +60,6 @@ __global__ void count_diff(const float* a, const float* b, size_t n, unsigned lo
   if (c) atomicAdd(cnt, c);
 }
 
-template <int ROT, bool IL = false, int WGS_PER_CU = 2>
-float run_persist(const float* qkv, float* out, const float* want, int n_seq, int S, int heads, int reps, const char* what, int delay = 0) {
-  constexpr int NW = 8, lds = 2 * (64 * 256 + 16 * (1024 + 64));
-  auto kern = attn_f32_persist_kernel<NW, ROT, IL>;
-  HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipDeviceProp_t prop;
-  HIP_OK(hipGetDeviceProperties(&prop, 0));
-  const int n_items = n_seq * heads, grid = std::min(n_items, WGS_PER_CU * prop.multiProcessorCount);
-  const size_t no = (size_t)n_seq * S * heads * 64;
-  HIP_OK(hipMemset(out, 0xFF, no * 4));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, qkv, out, S, heads, n_items, delay);
-  unsigned long long* cnt;
-  HIP_OK(hipMalloc(&cnt, 8));
-  HIP_OK(hipMemset(cnt, 0, 8));
-  count_diff<<<2048, 256>>>(out, want, no, cnt);
-  unsigned long long h = 0;
-  HIP_OK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipFree(cnt));
-  hipEvent_t a, b;
-  HIP_OK(hipEventCreate(&a));
-  HIP_OK(hipEventCreate(&b));
-  float best = 1e9f;
-  for (int round = 0; round < 4; ++round) {
-    HIP_OK(hipEventRecord(a, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, qkv, out, S, heads, n_items, delay);
-    HIP_OK(hipEventRecord(b, 0));
-    HIP_OK(hipEventSynchronize(b));
-    float ms;
-    HIP_OK(hipEventElapsedTime(&ms, a, b));
-    if (round) best = std::min(best, ms / reps);
-  }
-  printf("persistent  %-38s %8.3f ms   %llu of %zu values differ from the one-shot kernel\n", what, best, h, no);
-  return best;
-}
-
 int main(int argc, char** argv) {
   const int n_seq = argc > 1 ? atoi(argv[1]) : 1024, reps = argc > 2 ? atoi(argv[2]) : 10, S = 197, heads = 12;
   const size_t nq = (size_t)n_seq * S * 3 * heads * 64, no = nq / 3;
@@ -115,12 +79,7 @@ int main(int argc, char** argv) {
   run<6>(qkv, out, n_seq, S, heads, reps, "no S MFMAs (VALU stand-in)");
   run<0, 7>(qkv, out, n_seq, S, heads, reps, "7 waves per workgroup (14 tile slots)");
   run<0>(qkv, out, n_seq, S, heads, reps, "product kernel (again)");
-  float* out2;
-  HIP_OK(hipMalloc(&out2, no * 4));
-  run_persist<0>(qkv, out2, out, n_seq, S, heads, reps, "2 workgroups per CU, fixed roles");
-  run_persist<5>(qkv, out2, out, n_seq, S, heads, reps, "2 workgroups per CU, roles + 5 per item");
-  run_persist<0>(qkv, out2, out, n_seq, S, heads, reps, "fixed roles, random start within 16 k cycles", -16);
-  run_persist<0, true>(qkv, out2, out, n_seq, S, heads, reps, "fixed roles, S chains of two key tiles interleaved");
+  // (the persistent-workgroup form - bitwise equal, 6 % slower - was removed in round 5: profiles/r04_attn_persist_lab.log)
   run<0>(qkv, out, n_seq, S, heads, reps, "product kernel (again)");
   return 0;
 }

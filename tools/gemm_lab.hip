@@ -4,9 +4,6 @@
 // For every (shape, variant): checks 8192 sampled outputs against a naive fp32 dot product of the same bf16 operands,
 // then times `reps` back-to-back launches with hipEvents on random (never zero-filled) operands.
 #include "gemm_kernel.h"
-#include "gemm_wreg_lab.h"
-#include "gemm_deep_lab.h"
-#include "gemm_ring_lab.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -102,63 +99,8 @@ void launch_pipelined(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles < cap ? tiles : cap), dim3(WM * WN * 64), lds, st, a);
 }
 
-template <int EPI, int ABL, int SCHED = 0>
-void launch_wreg(const GemmArgs& a, hipStream_t st) {  // a.aux: the weight in fragment order (pack_w_frag_kernel)
-  constexpr int lds = 2 * 512 * ROWB + 8 * 2048 + 2048;
-  auto kern = gemm_wreg_kernel<256, 256, 2, 4, EPI, ABL, 1, SCHED>;
-  static bool configured = false;
-  if (!configured) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
-}
-
-// 256 x 128 workgroup tile, 8 waves of 64 x 64: 64 accumulator registers, room for two register sets of weight fragments.
-// a.bias .. unchanged; a.P carries the SECOND packed weight (128-column tiles) as an offset in bytes from a.aux (lab hack)
-template <int EPI, int ABL>
-void launch_wreg_narrow(const GemmArgs& a0, hipStream_t st) {
-  constexpr int BM = 256, BN = 128, WM = 4, WN = 2;
-  constexpr int lds = 2 * (BM + BN) * ROWB + 8 * 2048 + 2048;
-  auto kern = gemm_wreg_kernel<BM, BN, WM, WN, EPI, ABL, 1, 0>;
-  static bool configured = false;
-  if (!configured) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
-  GemmArgs a = a0;
-  a.aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a0.aux) + (size_t)a0.gR * 1024);  // second pack, KiB offset
-  a.gR = 0;
-  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
-}
-
-template <int EPI, int ABL>
-void launch_deep(const GemmArgs& a, hipStream_t st) {
-  constexpr int lds = 4 * 512 * 64 + 8 * 2048 + 2048;
-  auto kern = gemm_deep_kernel<EPI, ABL>;
-  static bool configured = false;
-  if (!configured) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
-}
-
-template <int EPI, int ABL>
-void launch_ring(const GemmArgs& a, hipStream_t st) {
-  constexpr int lds = 4 * 512 * 64 + 2048;
-  auto kern = gemm_ring_kernel<EPI, ABL>;
-  static bool configured = false;
-  if (!configured) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
-}
+// (the lab kernels whose results were negative - weights from registers, the four-stage BK = 32 kernel, the four-stage ring - were
+// removed in round 5; their logs are profiles/r01_lab23_deep.log, r03_gemm_lab_wreg*.log, r03_gemm_lab_ring.log)
 
 #include "gemm_lab_variants.inc"
 

@@ -2,7 +2,7 @@
 // fp32 operands on sampled outputs (next to the three-plane bf16 kernel, gemm_split3.h, on the same operands), timing on the
 // four block shapes, ablations, and what the fp16 matrix cores do with subnormal inputs.  Not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fitclip_amd/csrc -I include tools/split2_lab.hip -o tools/bin/split2_lab
-//   tools/bin/split2_lab [M] [reps] [rounds] [activation scale] [weight scale]
+//   tools/bin/split2_lab [M] [reps] [rounds] [activation scale] [weight scale] [only variants whose name contains this]
 #include "gemm_split2.hip"
 #include "gemm_split3.hip"
 
@@ -205,6 +205,12 @@ int main(int argc, char** argv) {
             {"x2 f32 spread2 rot0", launch_x2<EPI_BIAS_F32, 0, 2>, 0, 0, 1}, {"x2 f32 spread2 rot2", launch_x2<EPI_BIAS_F32, 0, 2>, 0, 0, 3},
             {"x2 f32 ABL2 same tile", launch_x2<EPI_BIAS_F32, 2, 2>, 0, 0}, {"x2 f32 ABL3 no-store", launch_x2<EPI_BIAS_F32, 3, 2>, 0, 0},
             {"x2 f32 ABL1 no-loads", launch_x2<EPI_BIAS_F32, 1, 2>, 0, 0}, {"x2 f32 ABL6 mfma only", launch_x2<EPI_BIAS_F32, 6, 2>, 0, 0}};
+    }
+    if (argc > 6) {  // (PMC passes: few dispatches - only the variants asked for)
+      std::vector<V> keep;
+      for (const V& v : vs)
+        if (strstr(v.name, argv[6])) keep.push_back(v);
+      vs = keep;
     }
     auto args_for = [&](const V& v) {
       GemmArgs b = a;
