@@ -12,6 +12,7 @@
 namespace fc {
 void set_error(const std::string&) {}
 hipError_t raise_dynamic_lds(const void* f, int bytes) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+int device_cus() { return 256; }
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

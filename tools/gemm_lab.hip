@@ -128,15 +128,9 @@ int main(int argc, char** argv) {
     fill_kernel<<<2048, 256, 0, st>>>(A, (size_t)M * sh.K, 1u, 1.0f);
     fill_kernel<<<2048, 256, 0, st>>>(W, (size_t)sh.N * sh.K, 2u, 2.0f / sqrtf((float)sh.K));
     fill_f32_kernel<<<64, 256, 0, st>>>(bias, sh.N, 3u);
-    bf16x8* Wp;
-    const size_t pack_bytes = (size_t)((sh.N + 255) / 256) * 256 * sh.K * 2;  // (a multiple of 1 KiB)
-    HIP_OK(hipMalloc(&Wp, 2 * pack_bytes));
-    pack_w_frag_kernel<<<1024, 256, 0, st>>>(W, Wp, sh.N, sh.K, sh.K, 256);
-    pack_w_frag_kernel<<<1024, 256, 0, st>>>(W, reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Wp) + pack_bytes), sh.N, sh.K, sh.K, 128);
     GemmArgs a{};
-    a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = reinterpret_cast<const float*>(Wp); a.alpha = 1.f;
+    a.A = A; a.W = W; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K; a.lda = sh.K; a.ldw = sh.K; a.ldc = sh.N; a.P = 0;
-    a.gR = (int)(pack_bytes / 1024);  // (lab: where the 128-column pack starts; the kernels under test ignore gR)
     for (const Variant& v : variants) {
       HIP_OK(hipMemsetAsync(C, 0, (size_t)M * sh.N * 2, st));
       v.launch(a, st);
@@ -173,7 +167,6 @@ int main(int argc, char** argv) {
              sh.K, v.name, ms, tf, tf / 2500.0, worst, worst < 2e-2f ? "ok" : "WRONG(expected for ablations)");
       fflush(stdout);
     }
-    HIP_OK(hipFree(Wp));
     HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(C)); HIP_OK(hipFree(bias)); HIP_OK(hipFree(err));
   }
   return 0;
