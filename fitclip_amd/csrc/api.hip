@@ -3,6 +3,7 @@
 #include "../../include/fitclip_hip.h"
 #include "common.h"
 #include "handle.h"
+#include <cstdlib>
 
 #include <cstdarg>
 #include <map>
@@ -252,6 +253,17 @@ struct TowerEntry {
   const float *cls, *pos0, *pre_w, *pre_b;
 };
 
+#ifdef FITCLIP_LAB
+// (tools/ only: libfitclip_hip_lab.so) FITCLIP_LAB_SKIP_LN=1: the LayerNorm launches of blocks 1.. are skipped - the GEMMs run on
+// the first block's normalised rows, results are meaningless - to time the CEILING of fusing LayerNorm into the GEMMs
+static bool lab_skip_ln() {
+  static const bool v = [] { const char* e = getenv("FITCLIP_LAB_SKIP_LN"); return e && atoi(e) != 0; }();
+  return v;
+}
+#else
+static constexpr bool lab_skip_ln() { return false; }
+#endif
+
 int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal,
                const float* fin_w, const float* fin_b, const int* pool_idx, long pool_step, hipStream_t st,
                const TowerEntry* entry = nullptr) {
@@ -267,7 +279,7 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
                                    kind, M, w, st));
     } else if (l == 0) {
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
-    } else {
+    } else if (!lab_skip_ln()) {
       ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, w, kind, M, w, st));
     }
@@ -292,7 +304,7 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
       return launch_layernorm(xp, w, nullptr, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);
     }
     FC_TRY(gemm(h, EPI_RESID_F32, s.xn, b.out_w, b.out_b, s.x, nullptr, M, w, w, w, 0, st));
-    {
+    if (!(lab_skip_ln() && l > 0)) {
       ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, w, kind, M, w, st));
     }

@@ -1,0 +1,32 @@
+"""What fusing the block LayerNorms into the GEMMs could buy the fp32 headline AT MOST: the bench step (256 clips x 8 frames + 256
+texts, fp32) with the lab library (`python -m fitclip_amd.build --lab`), once as shipped and once with FITCLIP_LAB_SKIP_LN=1 (the
+LayerNorm launches of blocks 1.. skipped; results meaningless, timing valid).  Two child processes (the switch is read once).
+    python tools/ln_ceiling.py"""
+import json, os, subprocess, sys
+repo = os.environ.get("GRAFT_REPO_ROOT", os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+child = r'''
+import os, sys, time, torch
+sys.path.insert(0, %r)
+from fitclip_amd import synth
+from fitclip_amd.clip_model import build_clip
+from fitclip_amd.encoder import ClipVideoTextEncoder
+d = synth.VIT_B_16
+enc = ClipVideoTextEncoder(build_clip(synth.make_state_dict(d, seed=42), precision="fp32", device="cuda:0"), num_frames=8)
+g = torch.Generator(device="cuda").manual_seed(0)
+video = torch.randn((256, 8, 3, 224, 224), generator=g, device="cuda").clamp_(-2.5, 2.5)
+ids = torch.from_numpy(synth.make_text(256, d, seed=1)).cuda()
+with torch.no_grad():
+    for _ in range(2): enc(video=video, text={"input_ids": ids})
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): enc(video=video, text={"input_ids": ids})
+    torch.cuda.synchronize(); print((time.perf_counter() - t0) / 5 * 1e3)
+''' % repo
+res = {}
+for skip in ("0", "1", "0", "1"):
+    env = {**os.environ, "FITCLIP_HIP_LIB": os.path.join(repo, "tools/bin/libfitclip_hip_lab.so"), "FITCLIP_LAB_SKIP_LN": skip}
+    out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res.setdefault(skip, []).append(float(out.stdout.strip().splitlines()[-1]))
+a, b = min(res["0"]), min(res["1"])
+print(json.dumps({"fp32_step_ms": res["0"], "fp32_step_ms_without_block_layernorms": res["1"],
+                  "ceiling_of_layernorm_fusion": f"{(a - b) / a * 100:.2f} % of the step ({a:.1f} -> {b:.1f} ms; 256 / {a / 1e3:.4f} = {256e3 / a:.1f} -> {256e3 / b:.1f} pairs/s)"}))

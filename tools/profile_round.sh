@@ -54,8 +54,10 @@ fi
 pmc_extra=""
 if [ "$prec" = c3 ]; then
   common="--config c3 --no-cpu-baseline --headline-only"
-  # (PMC passes serialise every dispatch: an epoch of 128 batches x ~330 launches takes many minutes under --pmc and has crashed
-  # the profiler; 8 batches of 32 clips run the same kernels on the same shapes)
+  # (a full epoch - 128 batches x ~330 launches = 42 k dispatches - cannot be profiled under --pmc: from some thousands of
+  # intercepted dispatches on (between 2.6 k and 10.5 k) the queue aborts with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT, raised
+  # by the runtime on a packet the profiler's interception rewrote; the same run WITHOUT --pmc completes - measured in
+  # tools/pmc_scaling_probe.py, profiles/r05_pmc_scaling_probe.log.  8 batches of 32 clips run the same kernels on the same shapes)
   pmc_extra="--total-clips 256"
 elif [ "$prec" = fp32x6 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
