@@ -839,12 +839,13 @@ int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld_out, i
   return launch_split2_weight(w, (long)ld_in, out, (long)ld_out, (long)rows, K, scale2, st);
 }
 int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float* scale2, const float* bias, void* C, int32_t M,
-                   int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, fc_stream st) {
+                   int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, int32_t cut, fc_stream st) {
   GemmArgs a{};
   a.A = A2; a.W = W2; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f; a.wscale = scale2; a.sat_flag = sat_flag;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc;
   if (!A2 || !W2 || !C || !scale2) return fail(FC_EINVAL, "fc_gemm_split2: null operand");
-  return launch_gemm_split2(epilogue, a, st);
+  if (cut < 0 || cut > 2) return fail(FC_EINVAL, "fc_gemm_split2: cut %d", cut);
+  return launch_gemm_split2(epilogue, a, st, cut);
 }
 
 int fc_profile_enable(fc_handle* h, int32_t max_records) {

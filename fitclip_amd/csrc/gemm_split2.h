@@ -30,12 +30,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // issue slot of LDS-DMA piece idx (0..3 activation rows, 4..7 weight rows) of a wave: -1 = in the hand-over (a whole K-step
 // before its data is needed), u >= 0 = behind MFMA group u of the NEXT K-step (the stage was released by the hand-over barrier in
 // front of that step; the piece must land before group 7 of the same step waits for it, so only the first half is used)
-constexpr int x2_piece_slot(int spread, int idx) {
+constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
   switch (spread) {
-    case 1: return idx < 4 ? -1 : 0;      // A in the hand-over, W behind group 0
+    case 1: return idx < lpa ? -1 : 0;    // A in the hand-over, W behind group 0
     case 2: return idx / 2 - 1;           // 2 in the hand-over, 2 behind each of groups 0, 1, 2
-    case 3: return idx / 2;               // 2 behind each of groups 0..3
-    case 4: return idx < 4 ? -1 : (idx - 4) / 2;  // A in the hand-over, W behind groups 0, 1
+    case 3: return idx / 2;               // 2 behind each of groups 0..3 (128-row tiles, 6 pieces: groups 0..2 of their 4)
+    case 4: return idx < lpa ? -1 : (idx - lpa) / 2;  // A in the hand-over, W behind groups 0, 1
     default: return -1;
   }
 }
@@ -43,14 +43,18 @@ constexpr int x2_piece_slot(int spread, int idx) {
 // ABL (tools/split2_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 2 = every workgroup stages the operand rows
 // of tile (0, 0) (all loads hit L2); 3 = no epilogue; 6 = no loads, no waits, no epilogue (MFMA + LDS reads only)
 // RW: residual rows requested RW tiles ahead (EPI_RESID3_F32); RR: tiles dealt round robin instead of the XCD panel ranges
-template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 2, int RR = 0>
+// BMT = 128: tiles of 128 rows (wave tile 64 x 64, half the MFMAs per K-step for the same weight tile: less efficient per FLOP) for
+// the TAIL of a launch whose 256-row tiles would not fill whole rounds over the compute units (gemm_split2.hip: plan).  An output
+// element sees the same K order and the same chain of 32 x 32 x 16 products whatever the tile height: bit-identical rows.
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 2, int RR = 0, int BMT = 256>
 __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
-  constexpr int TM = BM / WM, TN = BN / WN;        // 128 x 64 per wave
-  constexpr int FM = TM / 32, FN = TN / 32;        // 4 x 2 MFMA tiles of 32 x 32
+  constexpr int BM = BMT, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int TM = BM / WM, TN = BN / WN;        // 128 (64) x 64 per wave
+  constexpr int FM = TM / 32, FN = TN / 32;        // 4 (2) x 2 MFMA tiles of 32 x 32
   constexpr int NG = 2 * FM;                       // MFMA groups per K-step: (k-half, row tile)
-  constexpr int STAGE = (BM + BN) * ROWB;          // 65536
-  constexpr int LPA = BM / 8 / NW, LPB = BN / 8 / NW, LPW = LPA + LPB;  // LDS-DMA pieces per wave and stage: 4 + 4
+  constexpr int STAGE = (BM + BN) * ROWB;          // 65536 (49152)
+  constexpr int LPA = BM / 8 / NW, LPB = BN / 8 / NW, LPW = LPA + LPB;  // LDS-DMA pieces per wave and stage: 4 (2) + 4
+  static_assert(BM == 256 || BM == 128, "tile height");
   constexpr int OFF_STG = 2 * STAGE;               // 8 patches of 2 KiB
   constexpr int OFF_BIAS = OFF_STG + NW * 2048;    // 2 x 1 KiB
   constexpr bool kOutX2 = EPI == EPI_GELU_X2;
@@ -226,14 +230,14 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
             if (ABL != 1 && ABL < 5) {
               if (kt + 2 < nk) {
                 static_for<LPW>([&](auto I) {
-                  if constexpr (x2_piece_slot(SPREAD, decltype(I)::value) < 0) stage_piece(par, kt + 2, I);
+                  if constexpr (x2_piece_slot(SPREAD, decltype(I)::value, LPA) < 0) stage_piece(par, kt + 2, I);
                 });
               } else if (has_next) {
                 if (kt + 2 == nk) {
                   tile_sources(tnext, m0, n0);
                   bias_load((it + 1) & 1, n0);
                   static_for<LPW>([&](auto I) {
-                    if constexpr (x2_piece_slot(SPREAD, decltype(I)::value) < 0) stage_piece(par, 0, I);
+                    if constexpr (x2_piece_slot(SPREAD, decltype(I)::value, LPA) < 0) stage_piece(par, 0, I);
                   });
                 } else {
                   stage_load(par, 1);  // always a burst: it has to be older than the epilogue stores (counted vmcnt)
@@ -264,15 +268,15 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws[j], af[u & 1][1], acc[i][j], 0, 0, 0);
         if constexpr (SPREAD > 0 && ABL != 1 && ABL < 5 && u + 1 < NG) {
-          constexpr bool any = x2_piece_slot(SPREAD, 0) == u || x2_piece_slot(SPREAD, 1) == u || x2_piece_slot(SPREAD, 2) == u ||
-                               x2_piece_slot(SPREAD, 3) == u || x2_piece_slot(SPREAD, 4) == u || x2_piece_slot(SPREAD, 5) == u ||
-                               x2_piece_slot(SPREAD, 6) == u || x2_piece_slot(SPREAD, 7) == u;
+          constexpr bool any = x2_piece_slot(SPREAD, 0, LPA) == u || x2_piece_slot(SPREAD, 1, LPA) == u || x2_piece_slot(SPREAD, 2, LPA) == u ||
+                               x2_piece_slot(SPREAD, 3, LPA) == u || x2_piece_slot(SPREAD, 4, LPA) == u || x2_piece_slot(SPREAD, 5, LPA) == u ||
+                               (LPW > 6 && (x2_piece_slot(SPREAD, 6, LPA) == u || x2_piece_slot(SPREAD, 7, LPA) == u));
           if constexpr (any) {
             // K-step kt + 1 (or K-step 0 of the next tile) into the stage the previous hand-over released
             if (kt > 0 && (kt + 1 < nk || has_next)) {
               const int lk = kt + 1 < nk ? kt + 1 : 0;
               static_for<LPW>([&](auto I) {
-                if constexpr (x2_piece_slot(SPREAD, decltype(I)::value) == u) stage_piece(par ^ 1, lk, I);
+                if constexpr (x2_piece_slot(SPREAD, decltype(I)::value, LPA) == u) stage_piece(par ^ 1, lk, I);
               });
             }
           }

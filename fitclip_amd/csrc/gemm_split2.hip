@@ -8,19 +8,44 @@ namespace fc {
 
 namespace {
 
-constexpr int kSplit2Lds = 2 * 512 * 128 + 8 * 2048 + 2048;  // two stages, eight patches, two bias slices
+constexpr int split2_lds(int bm) { return 2 * (bm + 256) * 128 + 8 * 2048 + 2048; }  // two stages, eight patches, two bias slices
+[[maybe_unused]] constexpr int kSplit2Lds = split2_lds(256);   // (tools/split2_lab)
 
-template <int EPI, int RW = 2>
-int launch_x2_variant(const GemmArgs& a, hipStream_t stream) {
-  // SPREAD = 3: the LDS-DMA pieces of a K-step are issued two at a time behind the first four MFMA groups of the step before it is
+template <int EPI, int RW, int BMT>
+int launch_x2_tiles(const GemmArgs& a, hipStream_t stream) {
+  // SPREAD = 3: the LDS-DMA pieces of a K-step are issued two at a time behind the first MFMA groups of the step before it is
   // needed, none in the hand-over (tools/split2_lab: 2 - 4 % over a burst at the hand-over on all four block shapes)
-  auto kern = gemm_split2_kernel<EPI, 0, 3, RW, 0>;
-  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), kSplit2Lds) != hipSuccess)
-    return fail(FC_ELAUNCH, "gemm_split2: cannot raise dynamic LDS to %d bytes", kSplit2Lds);
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), kSplit2Lds, stream, a);
+  auto kern = gemm_split2_kernel<EPI, 0, 3, RW, 0, BMT>;
+  constexpr int lds = split2_lds(BMT);
+  if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
+    return fail(FC_ELAUNCH, "gemm_split2: cannot raise dynamic LDS to %d bytes", lds);
+  const int tiles = ((a.M + BMT - 1) / BMT) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), lds, stream, a);
   FC_CHECK_LAUNCH("gemm_split2");
   return FC_OK;
+}
+
+// Tile height.  The kernel is persistent over 256 x 256 tiles; a launch with fewer such tiles than compute units leaves CUs idle,
+// and 128-row tiles (half the MFMAs per staged weight tile: ~0.87 of the big tile's efficiency) then double the number of busy
+// CUs: out_proj of a 32-frame call (6304 rows, 75 tiles) 0.098 -> 0.068 ms, c_proj 0.313 -> 0.229, QKV 0.098 -> 0.074
+// (tools/x2_cut_probe.py, profiles/r05_x2_cut_probe.log).  Above that the big tile wins - also where a round model says it should
+// not: at 25 216 rows (the reference-shaped call of 128 frames) out_proj is 297 tiles = "two rounds for 1.16 rounds of work", yet
+// 256-row tiles take 0.129 ms, 128-row tiles 0.121, and the fp32 kernel's remedy - a head of whole rounds plus a tail launch of
+// half tiles - 0.191: this kernel runs at the chip's power limit (1.6 - 1.8 GHz, matrix pipe busy 0.6 - 0.7), the CUs that still
+// hold tiles speed up when the others run dry, and a second launch only adds its fill and drain.  No head + tail cut here.
+// Rows are independent and an element's K order only depends on its column tile: the result does not depend on the tile height.
+// `force`: 0 = by tile count, 1 = 256-row tiles, 2 = 128-row tiles (tests).
+bool x2_use_half_tiles(int M, int N, int cus, int force) {
+  if (force == 1) return false;
+  if (force == 2) return true;
+  const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+  return tiles256 <= cus;
+}
+
+template <int EPI, int RW = 2>
+int launch_x2_variant(const GemmArgs& a, hipStream_t stream, int force) {
+  return x2_use_half_tiles(a.M, a.N, device_cus(), force) ? launch_x2_tiles<EPI, RW, 128>(a, stream)
+                                                          : launch_x2_tiles<EPI, RW, 256>(a, stream);
 }
 
 // fp32 rows -> x2 rows: thread per (row, line of 32 columns, quarter): 8 values -> 16 bytes of either plane; the four threads of a
@@ -113,7 +138,7 @@ bool gemm_split2_ok(const GemmArgs& a) {
          ((uintptr_t)a.bias & 15) == 0 && (size_t)256 * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);
 }
 
-int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream) {
+int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int force_cut) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail(FC_EINVAL, "gemm_split2: empty problem %dx%dx%d", a.M, a.N, a.K);
   if (a.K % 64 || a.K < 128) return fail(FC_EINVAL, "gemm_split2: K=%d must be a multiple of 64, at least 128", a.K);
   if (a.N % 32) return fail(FC_EINVAL, "gemm_split2: N=%d must be a multiple of 32", a.N);
@@ -132,14 +157,14 @@ int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream) {
   switch (epilogue) {
     case EPI_BIAS_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);
-      return launch_x2_variant<EPI_BIAS_F32>(b, stream);
+      return launch_x2_variant<EPI_BIAS_F32>(b, stream, force_cut);
     case EPI_RESID3_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);
-      return launch_x2_variant<EPI_RESID3_F32, 2>(b, stream);
+      return launch_x2_variant<EPI_RESID3_F32, 2>(b, stream, force_cut);
     case EPI_GELU_X2:
       if (a.ldc % 64 || a.ldc < x2_row_elems(a.N) || ((uintptr_t)a.C & 127))
         return fail(FC_EINVAL, "gemm_split2: the x2 output needs 128-byte aligned rows of >= 2 N fp16 (ldc=%d)", a.ldc);
-      return launch_x2_variant<EPI_GELU_X2>(b, stream);
+      return launch_x2_variant<EPI_GELU_X2>(b, stream, force_cut);
   }
   return fail(FC_EINVAL, "gemm_split2: epilogue %d", epilogue);
 }

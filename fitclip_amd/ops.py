@@ -223,11 +223,12 @@ def x2_planes(x2: torch.Tensor):
 
 
 def gemm_split2(a2: torch.Tensor, w2: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, epilogue: int = EPI_BIAS_F32,
-                out: Optional[torch.Tensor] = None, flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, flag: Optional[torch.Tensor] = None, cut: int = 0) -> torch.Tensor:
     """epilogue(A @ W^T) for x2 operands a2 [M, 2 K] (`split2`, LayerNorm / attention x2 outputs, a previous EPI_GELU_X2 GEMM) and
     (w2 [N, 2 K], scale) from `split2_weight`: three fp16 MFMA products per fp32 product, fp32 accumulate (fc_gemm_split2).
     EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X2 -> x2 rows [M, 2 N] of QuickGELU(A @ W^T + bias); EPI_RESID3_F32: `out`
-    (float32 [M, N]) += A @ W^T + bias, in place."""
+    (float32 [M, N]) += A @ W^T + bias, in place.  `cut` (tests): tile height - 0 = by tile count, 1 = 256 rows, 2 = 128 rows; the
+    result does not depend on it."""
     _dev(a2, "a2", torch.float16), _dev(w2, "w2", torch.float16), _dev(bias, "bias", torch.float32), _dev(scale, "scale", torch.float32)
     if a2.dim() != 2 or w2.dim() != 2 or a2.shape[1] != w2.shape[1] or a2.shape[1] % 64:
         raise ValueError(f"x2 operands need matching [rows, 2 K] shapes, got {tuple(a2.shape)} and {tuple(w2.shape)}")
@@ -246,7 +247,7 @@ def gemm_split2(a2: torch.Tensor, w2: torch.Tensor, scale: torch.Tensor, bias: t
         _dev(flag, "flag", torch.int32)
     with torch.cuda.device(a2.device):
         _lib.check(_lib.load().fc_gemm_split2(epilogue, a2.data_ptr(), w2.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                              M, N, K, a2.stride(0), w2.stride(0), out.stride(0), _ptr(flag), _lib.current_stream()),
+                                              M, N, K, a2.stride(0), w2.stride(0), out.stride(0), _ptr(flag), cut, _lib.current_stream()),
                    "fc_gemm_split2")
     return out
 

@@ -132,6 +132,28 @@ def test_residual_epilogue_is_the_bias_epilogue_plus_the_stream(M, N, K):
     assert torch.equal(got[:M], want) and torch.equal(got[M:], x[M:])
 
 
+@pytest.mark.parametrize("epi", ["bias", "resid", "gelu"])
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 2304, 768), (25216, 768, 3072), (7000, 3072, 768), (130, 768, 768)])
+def test_tile_height_is_bit_invisible(M, N, K, epi):
+    """Launches with fewer 256-row tiles than CUs run on 128-row tiles (twice the busy CUs): an element sees the same K order and
+    the same product chain whatever tile holds it, so the automatic choice, 256-row and 128-row tiles give the same bits."""
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    a2 = ops.split2(torch.randn(M, K, device=DEV, generator=g))
+    w2, sc = ops.split2_weight(torch.randn(N, K, device=DEV, generator=g) / K ** 0.5)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M, N, device=DEV, generator=g)
+    outs = []
+    for cut in (1, 0, 2):
+        if epi == "resid":
+            o = x.clone()
+            ops.gemm_split2(a2, w2, sc, bias, ops.EPI_RESID3_F32, out=o, cut=cut)
+        else:
+            o = ops.gemm_split2(a2, w2, sc, bias, ops.EPI_GELU_X2 if epi == "gelu" else ops.EPI_BIAS_F32, cut=cut)
+        outs.append(o)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_gemm_split2_rejects_bad_operands():
     a2 = torch.zeros(64, 256, dtype=torch.float16, device=DEV)
     sc = torch.ones(2, device=DEV)
