@@ -264,7 +264,30 @@ def training_leg(sd, video, ids, args, dims, device, clips=64, steps=2):
            "weights": "random init (seed 42) teacher, student = teacher perturbed by 5 %; AdamW lr 3e-7 (the reference's "
                       "3e-6 is tuned for pretrained towers and overshoots on random ones), the same batch every step",
            "losses": [round(x, 6) for x in losses], "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
-    del module, student, teacher
+    del module, teacher
+    torch.cuda.empty_cache()
+    # labelled variant: the FROZEN teacher in precision fp32x3 (fp32-accurate embeddings from the fp16 matrix cores; the student and
+    # every gradient stay on the fp32-input MFMA path).  Same batch, a fresh student: its first losses must agree with the above.
+    try:
+        student3 = ClipVideoTextEncoder(build_clip(synth.perturbed_state_dict(sd, dims, seed=5, rel=0.05), precision="fp32",
+                                                   device=device), num_frames=frames)
+        teacher3 = ClipVideoTextEncoder(build_clip(sd, precision="fp32x3", device=device), num_frames=frames)
+        module3 = TeacherStudentTrainer(student3, teacher3, init_temperature=0.05, lr=3e-7)
+        l3 = [module3.fit_step(batch)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            l3.append(module3.fit_step(batch))
+        torch.cuda.synchronize()
+        el3 = (time.perf_counter() - t0) / steps
+        teacher3.model.check_range()
+        out["with_fp32x3_teacher"] = {"ms_per_step": round(el3 * 1e3, 2), "pairs_per_s": round(n / el3, 2),
+                                      "first_loss_abs_delta_vs_fp32_teacher": abs(l3[0] - losses[0]),
+                                      "note": "teacher FLOPs run on the fp16 pipe (three products per fp32 product); not counted in `tflops`"}
+        del module3, student3, teacher3
+    except Exception as exc:  # (a labelled extra: it must not cost the leg)
+        out["with_fp32x3_teacher"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    del student
     torch.cuda.empty_cache()
     return out
 
