@@ -46,17 +46,19 @@ def one_kernel(a, needle, min_us, max_us, shape, epilogue):
     fetch_b = 2.0 * 1024.0 * mean(f["FETCH_SIZE"])
     write_b = 1024.0 * mean(w["WRITE_SIZE"])
     M, N, K = shape
-    esz = 2 if a.precision in ("bf16", "fp32x6") else 4
+    esz = 2 if a.precision in ("bf16", "fp32x6", "fp32x3") else 4
     # split-fp32 GEMMs (precision fp32x6; K is given as 6 K, the bf16 products): three bf16 planes per operand value = 6 bytes;
     # fp32 or three-plane rows out
-    out_b = M * N * (4 if epilogue.endswith("f32_out") else 6 if epilogue.endswith("x3_out") else esz)
+    out_b = M * N * (4 if epilogue.endswith("f32_out") or epilogue.endswith("x2_out") else 6 if epilogue.endswith("x3_out") else esz)
     if "residual" in epilogue:  # C += ..: the fp32 tile is read as well as written
         out_b = 2 * M * N * 4
     res = {"kernel_substring": needle, "min_duration_us": min_us, "max_duration_us": max_us,
            "launches_fetch": len(f["FETCH_SIZE"]), "launches_write": len(w["WRITE_SIZE"]),
            "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
            "shape": [M, N, K], "precision": a.precision, "epilogue": epilogue,
-           "algorithmic_bytes_per_launch": ((M * K + N * K) * esz if a.precision != "fp32x6" else (M + N) * (K // 6) * 6) + out_b}
+           # (fp32x6: K is 6 K, three bf16 planes = 6 bytes per operand value; fp32x3: K is 3 K, two fp16 planes = 4 bytes)
+           "algorithmic_bytes_per_launch": ((M + N) * (K // 6) * 6 if a.precision == "fp32x6" else (M + N) * (K // 3) * 4
+                                            if a.precision == "fp32x3" else (M * K + N * K) * esz) + out_b}
     if a.sq:
         s, durs = per_dispatch(a.sq, needle, min_us, max_us)
         sq = {k: round(mean(v)) for k, v in s.items()}

@@ -2,7 +2,8 @@
 # Reproduces the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun, from the repo root):
 #   tools/profile_round.sh r04 fp32        # the headline precision
 #   tools/profile_round.sh r04 bf16        # the secondary mode
-#   tools/profile_round.sh r04 fp32x6      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on)
+#   tools/profile_round.sh r05 fp32x3      # the split-fp32 leg (fp32 bench run with `fp32_split_mode` on: three fp16 products)
+#   tools/profile_round.sh r05 fp32x6      # the six-product split mode of rounds 2-4 (fp32 bench run with --split6)
 #   tools/profile_round.sh r04 c3          # bench.py --config c3 (encoder=wise, eval batches of 32 clips = 128 frames per call)
 # 1. kernel trace + stats of the bench command for that precision (CPU leg and the other precision off);
 # 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) and 4. an SQ pass for the dominant kernel (c_fc + QuickGELU GEMM).
@@ -42,6 +43,14 @@ elif [ "$prec" = bf16 ]; then
   steps=5; chunk=2048; rows=$((chunk * 197))
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|1000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi2E|1000|1e9|$rows|768|3072|bias_residual"
+elif [ "$prec" = fp32x3 ]; then
+  # fp32x3 = the split-fp32 leg of the fp32 bench run (round 5): the 2048 frames of a step run as 1024 + 1024; two-plane fp16
+  # operands, three fp16 products per fp32 product (the K below is 3 K).  c_fc (QuickGELU + x2 rows) has its own instantiation
+  # (epilogue 10; 2.4 ms at 1024 frames); c_proj shares epilogue 8 with out_proj and is the only one of the two above 1.5 ms
+  # (at 1024 frames: c_proj 2.3, out_proj 0.7)
+  steps=3; chunk=1024; rows=$((chunk * 197))
+  spec_fc="gemm_split2_kernel<10,|2000|1e9|$rows|3072|2304|bias_quickgelu_x2_out"
+  spec_proj="gemm_split2_kernel<8,|1500|1e9|$rows|768|9216|bias_residual_f32_out"
 else
   # fp32x6 = the split-fp32 leg of the fp32 bench run (the 2048 frames of a step run as 768 + 768 + 512; three-plane operands,
   # six bf16 products per fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation
@@ -59,8 +68,10 @@ if [ "$prec" = c3 ]; then
   # by the runtime on a packet the profiler's interception rewrote; the same run WITHOUT --pmc completes - measured in
   # tools/pmc_scaling_probe.py, profiles/r05_pmc_scaling_probe.log.  8 batches of 32 clips run the same kernels on the same shapes)
   pmc_extra="--total-clips 256"
-elif [ "$prec" = fp32x6 ]; then
+elif [ "$prec" = fp32x3 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
+elif [ "$prec" = fp32x6 ]; then
+  common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg --split6"
 else
   common="--precision $prec --no-bf16-mode --no-split-mode --no-cpu-baseline --no-train-leg"
 fi
@@ -75,7 +86,7 @@ echo "sq pass done"
 cd "$repo"
 find "$out/prof_trace_$prec" -name "*kernel_stats.csv" -exec cp {} "$keep/${tag}_bench_${prec}_kernel_stats.csv" \;
 trace=$(find "$out/prof_trace_$prec" -name "*kernel_trace.csv" | head -1)
-if [ "$prec" != fp32x6 ]; then  # (the split leg shares its trace with the fp32 leg: only the kernel table is kept)
+if [ "$prec" != fp32x6 ] && [ "$prec" != fp32x3 ]; then  # (the split legs share their trace with the fp32 leg: only the kernel table is kept)
   python3 tools/trace_summary.py "$trace" $chunk $([ "$prec" = c3 ] && echo fp32 || echo $prec) > "$keep/${tag}_bench_${prec}_trace_summary.txt"
 fi
 cp "$out/prof_trace_$prec.json" "$keep/${tag}_bench_${prec}_under_rocprof.json"
