@@ -1,6 +1,7 @@
 """Builds fitclip_amd/csrc/libfitclip_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m fitclip_amd.build [--force] [--save-temps]
+    python -m fitclip_amd.build --debug          # tools/bin/libfitclip_hip_debug.so: NaN / Inf scan behind every tower call
     python -m fitclip_amd.build --host-asan      # CPU sanitizer target: csrc/bpe.cpp under ASan + UBSan (tests/test_sanitize.py)
 """
 from __future__ import annotations
@@ -133,17 +134,20 @@ def audit_no_scratch(asm_path: Path, substrings) -> int:
 
 
 LAB_LIB = REPO / "tools" / "bin" / "libfitclip_hip_lab.so"
+DEBUG_LIB = REPO / "tools" / "bin" / "libfitclip_hip_debug.so"
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = True, lab: bool = False) -> Path:
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True, lab: bool = False, debug: bool = False) -> Path:
     """`lab=True` builds tools/bin/libfitclip_hip_lab.so with -DFITCLIP_LAB: the same sources plus the A/B switches the lab
-    scripts under tools/ read from the environment (select it with FITCLIP_HIP_LIB=...).  The product library never defines it."""
+    scripts under tools/ read from the environment (select it with FITCLIP_HIP_LIB=...).  The product library never defines it.
+    `debug=True` builds tools/bin/libfitclip_hip_debug.so with -DFITCLIP_DEBUG: every tower call scans its output for NaN / Inf
+    (a device-side count, one host synchronisation per call) and fails with the call's name."""
     hipcc = _hipcc()
-    objdir = CSRC / ("build_lab" if lab else "build")
+    objdir = CSRC / ("build_lab" if lab else "build_debug" if debug else "build")
     objdir.mkdir(exist_ok=True)
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-             "-fvisibility=hidden", "-DFITCLIP_BUILD"] + (["-DFITCLIP_LAB"] if lab else [])
-    lib_path = LAB_LIB if lab else LIB
+             "-fvisibility=hidden", "-DFITCLIP_BUILD"] + (["-DFITCLIP_LAB"] if lab else []) + (["-DFITCLIP_DEBUG"] if debug else [])
+    lib_path = LAB_LIB if lab else DEBUG_LIB if debug else LIB
     lib_path.parent.mkdir(exist_ok=True)
 
     def compile_one(src: str) -> Path:
@@ -204,4 +208,4 @@ if __name__ == "__main__":
     if "--host-asan" in sys.argv:
         print(build_host_asan())
     else:
-        print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, lab="--lab" in sys.argv))
+        print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, lab="--lab" in sys.argv, debug="--debug" in sys.argv))

@@ -198,6 +198,31 @@ int gemm(fc_handle* h, int epi, const void* A, const void* W, const float* bias,
     if (_rc != FC_OK) return _rc; \
   } while (0)
 
+#ifdef FITCLIP_DEBUG
+// Debug builds only (`python -m fitclip_amd.build --debug` -> tools/bin/libfitclip_hip_debug.so): every tower
+// call ends with a scan of its output for NaN / Inf and a HOST synchronisation - a tower that produced non-finite embeddings
+// returns FC_ELAUNCH naming the call instead of handing them to the scoring.  The product library never defines FITCLIP_DEBUG (it
+// allocates nothing and never synchronises).
+__global__ void __launch_bounds__(256) nonfinite_kernel(const float* __restrict__ x, size_t n, int* __restrict__ count) {
+  int c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += !isfinite(x[i]);
+  if (c) atomicAdd(count, c);
+}
+int debug_scan(const float* x, size_t n, hipStream_t st, const char* what) {
+  static thread_local int* d_count = nullptr;
+  if (!d_count && hipMalloc(reinterpret_cast<void**>(&d_count), sizeof(int)) != hipSuccess) return fail(FC_ENOMEM, "%s: debug scan", what);
+  int h = 0;
+  if (hipMemsetAsync(d_count, 0, sizeof(int), st) != hipSuccess) return fail(FC_ELAUNCH, "%s: debug scan", what);
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(256), dim3(256), 0, st, x, n, d_count);
+  if (hipMemcpyAsync(&h, d_count, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return fail(FC_ELAUNCH, "%s: debug scan", what);
+  return h ? fail(FC_ELAUNCH, "%s: %d of %zu output values are NaN or Inf (FITCLIP_DEBUG scan)", what, h, n) : FC_OK;
+}
+#define FC_DEBUG_SCAN(x, n, st, what) FC_TRY(debug_scan(x, n, st, what))
+#else
+#define FC_DEBUG_SCAN(x, n, st, what) do { } while (0)
+#endif
+
 struct Scratch {
   float* x;
   char* xn;
@@ -684,6 +709,7 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
   // the range flag follows the call to the host (pinned: no synchronisation; the NEXT call and fc_range_status read it)
   if (h->sat_flag && hipMemcpyAsync(h->sat_host, h->sat_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
     return fail(FC_ELAUNCH, "fc_encode_image: range flag copy");
+  FC_DEBUG_SCAN(out, (size_t)n * c.embed_dim, st, "fc_encode_image");
   return FC_OK;
 }
 
@@ -723,6 +749,7 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->tproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, tw, c.embed_dim, 0, st));
   }
+  FC_DEBUG_SCAN(out, (size_t)n * c.embed_dim, st, "fc_encode_text");
   return FC_OK;
 }
 

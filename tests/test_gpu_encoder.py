@@ -739,3 +739,47 @@ def test_bench_exits_nonzero_when_a_secondary_leg_fails():
     import json
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert line["value"] > 0 and line["failed_legs"] == ["cpu_baseline"] and "error" in line["cpu_baseline"]
+
+
+def test_debug_build_names_the_tower_that_produced_non_finite_values(tmp_path):
+    """SURVEY.md section 5 (NaN / Inf self-check in debug builds): `python -m fitclip_amd.build --debug` builds
+    tools/bin/libfitclip_hip_debug.so, whose tower calls scan their output on the device and fail with the call's name; the product
+    library has no such scan (no allocation, no synchronisation on the hot path).  Run in child processes: the library is chosen
+    once per process (FITCLIP_HIP_LIB)."""
+    import os
+    import subprocess
+    import sys
+    from fitclip_amd import build
+    lib = build.DEBUG_LIB
+    if not lib.exists():
+        pytest.skip("tools/bin/libfitclip_hip_debug.so is not built (python -m fitclip_amd.build --debug)")
+    child = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from fitclip_amd import synth, _lib
+from fitclip_amd.clip_model import build_clip
+d = synth.TINY
+sd = synth.make_state_dict(d, seed=42)
+frames = torch.from_numpy(synth.make_video(2, 2, d, seed=1)).reshape(-1, 3, d.image_resolution, d.image_resolution).cuda()
+ids = torch.from_numpy(synth.make_text(3, d, seed=1)).cuda()
+ok = build_clip(sd, precision="fp32", device="cuda")
+assert torch.isfinite(ok.encode_image(frames)).all() and torch.isfinite(ok.encode_text(ids)).all()
+bad = {k: np.array(v, copy=True) for k, v in sd.items()}
+bad[sys.argv[1]][0] = np.nan
+m = build_clip(bad, precision="fp32", device="cuda")
+try:
+    m.encode_image(frames) if sys.argv[1].startswith("visual") else m.encode_text(ids)
+    print("NO ERROR")
+except _lib.FitclipHipError as e:
+    print("ERROR:", e)
+''' % str(build.REPO)
+    for key, call in (("visual.ln_post.bias", "fc_encode_image"), ("ln_final.bias", "fc_encode_text")):
+        for path, expect_error in ((str(lib), True), (str(build.LIB), False)):
+            res = subprocess.run([sys.executable, "-c", child, key], capture_output=True, text=True, timeout=600,
+                                 env={**os.environ, "FITCLIP_HIP_LIB": path})
+            assert res.returncode == 0, res.stderr[-2000:]
+            last = res.stdout.strip().splitlines()[-1]
+            if expect_error:
+                assert last.startswith("ERROR:") and call in last and "NaN or Inf" in last, last
+            else:
+                assert last == "NO ERROR", last
