@@ -154,6 +154,30 @@ def test_tile_height_is_bit_invisible(M, N, K, epi):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 288, 128), (70, 32, 192), (513, 800, 256)])
+def test_ragged_column_tiles(M, N, K):
+    """N a multiple of 32 but not of the 256-column tile (partial last column tile: clamped weight rows, guarded stores), K at its
+    minimum and at an odd multiple of 64; all three epilogues against float64 / each other, rows and columns beyond left alone."""
+    g = torch.Generator(device=DEV).manual_seed(N)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    a2 = ops.split2(a)
+    w2, sc = ops.split2_weight(w)
+    ref = a.double() @ w.double().T + bias.double()
+    y = ops.gemm_split2(a2, w2, sc, bias)
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    x = torch.randn(M + 2, N, device=DEV, generator=g)
+    got = x.clone()
+    ops.gemm_split2(a2, w2, sc, bias, ops.EPI_RESID3_F32, out=got[:M])
+    assert torch.equal(got[:M], x[:M] + y) and torch.equal(got[M:], x[M:])
+    h2 = ops.gemm_split2(a2, w2, sc, bias, ops.EPI_GELU_X2)
+    want = ref * torch.sigmoid(1.702 * ref)
+    assert h2.shape == (M, 2 * N) and float((_value(h2) - want).abs().max() / want.abs().max()) < 4e-7
+    for cut in (1, 2):
+        assert torch.equal(ops.gemm_split2(a2, w2, sc, bias, cut=cut), y)
+
+
 def test_gemm_split2_rejects_bad_operands():
     a2 = torch.zeros(64, 256, dtype=torch.float16, device=DEV)
     sc = torch.ones(2, device=DEV)

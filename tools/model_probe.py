@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Throughput of the visual tower for the reference's CLIP ViT geometries (random weights): frames/s and TFLOP/s.
 
-    python tools/model_probe.py [B/16 B/32 L/14 L/14@336]
-"""
+    python tools/model_probe.py [--precision bf16|fp32|fp32x6|fp32x3] [B/16 B/32 L/14 L/14@336]
+
+With a split precision the embeddings are also compared with the fp32-MFMA path on 8 frames (the geometries whose sequence length
+has no fused split attention - 50, 257, 577 tokens - take the fp32 attention + a split pass) and the range flag is checked."""
 import sys
 import time
 
@@ -32,10 +34,15 @@ def flops_per_frame(d):
 
 
 def main():
-    names = sys.argv[1:] or list(GEOM)
+    args = sys.argv[1:]
+    precision = "bf16"
+    if args and args[0] == "--precision":
+        precision, args = args[1], args[2:]
+    names = args or list(GEOM)
     for name in names:
         d = synth.ClipDims(context_length=77, vocab_size=49408, transformer_layers=2, **GEOM[name])  # text tower unused
-        model = build_clip(synth.make_state_dict(d, seed=1), precision="bf16", device="cuda")
+        sd = synth.make_state_dict(d, seed=1)
+        model = build_clip(sd, precision=precision, device="cuda")
         frames = 1024 if "336" not in name else 256
         x = torch.randn(frames, 3, d.image_resolution, d.image_resolution, device="cuda")
         for _ in range(4):
@@ -47,8 +54,15 @@ def main():
             model.encode_image(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / reps
-        print(f"ViT-{name:9s} {frames / dt:9.0f} frames/s  {flops_per_frame(d) * frames / dt / 1e12:7.1f} TFLOP/s "
-              f"({flops_per_frame(d) / 1e9:.1f} GF/frame)", flush=True)
+        extra = ""
+        if precision.startswith("fp32x"):
+            model.check_range()
+            plain = build_clip(sd, precision="fp32", device="cuda")
+            a, b = model.encode_image(x[:8].contiguous()), plain.encode_image(x[:8].contiguous())
+            extra = f"  max |emb - fp32 path| {float((a - b).abs().max()):.2e} of max |emb| {float(b.abs().max()):.2f}"
+            del plain
+        print(f"ViT-{name:9s} {precision:7s} {frames / dt:9.0f} frames/s  {flops_per_frame(d) * frames / dt / 1e12:7.1f} TFLOP/s "
+              f"({flops_per_frame(d) / 1e9:.1f} GF/frame){extra}", flush=True)
         del model, x
         torch.cuda.empty_cache()
 
