@@ -15,7 +15,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 REPO = CSRC.parent.parent
 LIB = CSRC / "libfitclip_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm_split3.hip", "gemm_split2.hip", "attention.hip", "attention_split.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_split3.hip", "gemm_split2.hip", "attention.hip", "attention_split.hip", "attention_split2.hip", "rowops.hip", "score.hip", "wgrad.hip", "attention_bwd.hip", "backward.hip",
            "train.hip", "bpe.cpp"]
 HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", CSRC / "gemm_split3.h", CSRC / "gemm_split2.h", CSRC / "handle.h", CSRC / "unicode_ranges.inc",
            REPO / "include" / "fitclip_hip.h"]
@@ -29,6 +29,7 @@ NO_SCRATCH_AUDIT = {
     "gemm_split3.hip": ["gemm_split3_kernel"],
     "gemm_split2.hip": ["gemm_split2_kernel"],
     "attention_split.hip": ["attn_split_kernel"],
+    "attention_split2.hip": ["attn_split2_kernel"],
     "attention.hip": ["attn_f32_blocks_kernel", "attn_f32_mfma_kernel", "attn_bf16_v2_kernel"],
     "rowops.hip": ["layernorm_kernel", "layernorm_pair_kernel"],
     "wgrad.hip": ["gemm_tn_kernel"],   # (the KD training step: 24 % of its kernel time)

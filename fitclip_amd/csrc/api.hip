@@ -431,8 +431,8 @@ int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
     FC_TRY(gemm_x2(h, EPI_BIAS_F32, s.xn, b.in_w2, b.in_s2, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
-      if (attention_split_supported(S, 0)) {
-        FC_TRY(launch_attention_split(s.big, s.xn, n_seq, S, heads, st, KIND_X2, h->sat_flag));
+      if (attention_split2_supported(S, 0)) {
+        FC_TRY(launch_attention_split2(s.big, s.xn, n_seq, S, heads, st, h->sat_flag));
       } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
         FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
         FC_TRY(launch_split2_rows(s.d, w, s.xn, ld2, M, w, h->sat_flag, st));
@@ -838,6 +838,10 @@ int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, i
   if (precision == ATTN_SPLIT_X2) {  // the same kernel, x2 rows out (two fp16 planes: the operand format of fc_gemm_split2)
     if (causal) return fail(FC_EINVAL, "fc_attention: split-fp32 attention is not available for causal attention");
     return launch_attention_split(qkv, out, n_seq, S, heads, st, KIND_X2, nullptr);
+  }
+  if (precision == ATTN_SPLIT2) {  // three fp16 products per fp32 product (attention_split2.hip), x2 rows out
+    if (causal) return fail(FC_EINVAL, "fc_attention: split-fp32 attention is not available for causal attention");
+    return launch_attention_split2(qkv, out, n_seq, S, heads, st, nullptr);
   }
   return launch_attention(precision, qkv, out, n_seq, S, heads, causal, st);
 }

@@ -184,10 +184,16 @@ int launch_attention_x3(const void* qkv, void* out, int n_seq, int S, int heads,
 // matrix cores; non-causal, 193..208 tokens (the ViT's 197)
 constexpr int ATTN_SPLIT = 4;  // `precision` argument of fc_attention
 constexpr int ATTN_SPLIT_X2 = 5;  // ... the same kernel with x2 rows out
+constexpr int ATTN_SPLIT2 = 6;    // attention_split2.hip: both products as THREE fp16 products per fp32 product, x2 rows out
 bool attention_split_supported(int S, int causal);
 // out_kind: KIND_X3 (x3 rows) or KIND_X2 (x2 rows [n_seq * S, 2 * heads * 64 fp16 positions]; sat_flag as in GemmArgs)
 int launch_attention_split(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream, int out_kind = 3,
                            int* sat_flag = nullptr);
+
+// split-fp32 attention on two fp16 planes (attention_split2.hip): fp32 qkv in, x2 rows out, three fp16 products per fp32 product
+// with the cross terms in a second accumulator; non-causal, 193..208 tokens; sat_flag as in GemmArgs
+bool attention_split2_supported(int S, int causal);
+int launch_attention_split2(const void* qkv, void* out, int n_seq, int S, int heads, hipStream_t stream, int* sat_flag = nullptr);
 
 // --------------------------------------------------------------------------------------------- row ops
 // y[i] = LN(x[row(i)]) * gamma + beta.  row(i) = gather ? gather[i] : i; x row r at x + r * x_stride.

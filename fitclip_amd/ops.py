@@ -15,6 +15,7 @@ KIND_X3 = 3
 ATTN_SPLIT = 4  # fc_attention precision: split-fp32 attention (x3 rows out)
 KIND_X2 = 4     # row kernels: x2 rows out (two fp16 planes, csrc/common.h)
 ATTN_SPLIT_X2 = 5  # fc_attention precision: the split attention with x2 rows out
+ATTN_SPLIT2 = 6    # fc_attention precision: three fp16 products per fp32 product (attention_split2.hip), x2 rows out
 # KIND_X3: element-kind argument of the row kernels / attention: x3 rows out (three bf16 planes, csrc/common.h)
 
 
@@ -118,11 +119,14 @@ def add_layernorm(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, bet
 
 
 def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool = False,
-              three_plane: bool = False, split: bool = False, two_plane: bool = False) -> torch.Tensor:
+              three_plane: bool = False, split: bool = False, two_plane: bool = False, three_products: bool = False) -> torch.Tensor:
     """qkv [n_seq * seq_len, 3 * heads * 64] (float32 or bfloat16) -> [n_seq * seq_len, heads * 64]; `three_plane`
     (float32 qkv, non-causal, 113..224 tokens): x3 rows [.., 4 * heads * 64] of the fp32 result; `split` (193..208 tokens):
     x3 rows too, both products as six bf16 products per fp32 product on the bf16 matrix cores (fp32 accuracy); `split` with
-    `two_plane`: the same kernel, x2 rows [.., 2 * heads * 64] out (split2 layout)."""
+    `two_plane`: the same kernel, x2 rows [.., 2 * heads * 64] out (split2 layout); `three_products` (with `split` and `two_plane`):
+    both products as THREE fp16 products per fp32 product (attention_split2.hip: the attention of precision "fp32x3")."""
+    if three_products and not (split and two_plane):
+        raise ValueError("three_products is a form of the split attention with x2 rows out")
     if two_plane and not split:
         raise ValueError("x2 rows come from the split attention only (split=True)")
     three_plane = (three_plane or split) and not two_plane
@@ -133,7 +137,7 @@ def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: b
     out = (_x3_empty(n_seq * seq_len, D, qkv.device) if three_plane else _x2_empty(n_seq * seq_len, D, qkv.device) if two_plane
            else torch.empty((n_seq * seq_len, D), dtype=qkv.dtype, device=qkv.device))
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().fc_attention(ATTN_SPLIT_X2 if two_plane else ATTN_SPLIT if split else KIND_X3 if three_plane else _KIND[qkv.dtype],
+        _lib.check(_lib.load().fc_attention(ATTN_SPLIT2 if three_products else ATTN_SPLIT_X2 if two_plane else ATTN_SPLIT if split else KIND_X3 if three_plane else _KIND[qkv.dtype],
                                             qkv.data_ptr(), out.data_ptr(),
                                             n_seq, seq_len, heads, int(causal), _lib.current_stream()), "fc_attention")
     return out

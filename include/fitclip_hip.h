@@ -203,7 +203,9 @@ FC_API int fc_add_layernorm(float* x, int64_t x_stride, const void* delta, int64
  * precision 3: fp32 qkv in, x3 rows out (fc_split3 layout; non-causal, 113..224 tokens), the fp32 kernel's values.
  * precision 4: the same operands and layout, both products formed as six bf16 products per fp32 product on the bf16 matrix
  * cores (fc_gemm_split3's arithmetic; fp32 accuracy, not the fp32 kernel's bits; non-causal, 193..208 tokens): the attention
- * of the split_gemm mode.  precision 5: as 4, x2 rows out (fc_split2 layout): the attention of split_gemm = 2. */
+ * of the split_gemm = 1 mode.  precision 5: as 4, x2 rows out (fc_split2 layout).  precision 6: fp32 qkv in, x2 rows out, both
+ * products as THREE fp16 products per fp32 product (two fp16 planes per operand, the cross terms in a second accumulator;
+ * fp32 accuracy; non-causal, 193..208 tokens): the attention of split_gemm = 2. */
 FC_API int fc_attention(int32_t precision, const void* qkv, void* out, int32_t n_seq, int32_t S, int32_t heads,
                  int32_t causal, fc_stream stream);
 FC_API int fc_convert(const float* in, void* out, int32_t out_kind, size_t n, fc_stream stream);

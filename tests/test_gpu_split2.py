@@ -173,7 +173,7 @@ def test_ragged_column_tiles(M, N, K):
     assert torch.equal(got[:M], x[:M] + y) and torch.equal(got[M:], x[M:])
     h2 = ops.gemm_split2(a2, w2, sc, bias, ops.EPI_GELU_X2)
     want = ref * torch.sigmoid(1.702 * ref)
-    assert h2.shape == (M, 2 * N) and float((_value(h2) - want).abs().max() / want.abs().max()) < 4e-7
+    assert h2.shape == (M, 2 * N) and float((_value(h2) - want).abs().max() / want.abs().max()) < 1.5e-6   # (the GEMM's own error, through the GELU)
     for cut in (1, 2):
         assert torch.equal(ops.gemm_split2(a2, w2, sc, bias, cut=cut), y)
 
@@ -255,6 +255,44 @@ def test_split_attention_with_two_plane_output(S):
     assert float((_value(o2)[some] - ref).abs().max()) / float(ref.abs().max()) < 5e-6
     few = 7
     assert torch.equal(ops.attention(qkv[: few * S].contiguous(), few, S, heads, split=True, two_plane=True), o2[: few * S])
+
+
+@pytest.mark.parametrize("S", [197, 193, 208])
+def test_three_product_attention_has_fp32_accuracy(S):
+    """fc_attention precision 6 (attention_split2.hip): softmax(q k^T / 8) v with both products as THREE fp16 products per fp32
+    product (two planes per operand, scaled residuals, the cross terms in a second accumulator) - the attention of precision
+    "fp32x3".  Against float64 it must be as accurate as the fp32-MFMA kernel; a (sequence, head) pair's result must not depend on
+    how many pairs the persistent workgroups walk over (300 sequences: 3600 pairs on 256 workgroups) nor on the run."""
+    heads, n_seq = 12, 300
+    g = torch.Generator(device=DEV).manual_seed(S)
+    qkv = torch.randn(n_seq * S, 3 * heads * 64, device=DEV, generator=g) * 2.0   # scores of +-30: peaked rows too
+    qkv[: S, : heads * 64] *= 3.0
+    o2 = ops.attention(qkv, n_seq, S, heads, split=True, two_plane=True, three_products=True)
+    assert o2.shape == (n_seq * S, 2 * heads * 64) and o2.dtype == torch.float16 and bool(torch.isfinite(o2.float()).all())
+    some = torch.cat([torch.arange(0, 3 * S), torch.arange(150 * S, 151 * S), torch.arange((n_seq - 2) * S, n_seq * S)]).to(DEV)
+    ref = _attention_f64(qkv[some], some.numel() // S, S, heads)
+    o32 = ops.attention(qkv, n_seq, S, heads)
+    scale = float(ref.abs().max())
+    e3 = float((_value(o2)[some] - ref).abs().max()) / scale
+    e32 = float((o32[some].double() - ref).abs().max()) / scale
+    assert e3 < 5e-6 and e3 < 1.2 * e32 + 1e-7, (e3, e32)
+    assert float((_value(o2) - o32.double()).abs().max()) / scale < 1e-5          # EVERY element, against the fp32-MFMA kernel
+    assert torch.equal(ops.attention(qkv, n_seq, S, heads, split=True, two_plane=True, three_products=True), o2)  # run to run
+    few = 7                                                      # fewer pairs than workgroups: one pass each
+    assert torch.equal(ops.attention(qkv[: few * S].contiguous(), few, S, heads, split=True, two_plane=True, three_products=True), o2[: few * S])
+    tail = qkv[(n_seq - few) * S:].contiguous()
+    assert torch.equal(ops.attention(tail, few, S, heads, split=True, two_plane=True, three_products=True), o2[(n_seq - few) * S:])
+    # small and large operands alike (the planes are scale-free down to 2^-14): 1e-3 and 100 times the values above
+    for mag in (1e-3, 1e2):
+        q2 = qkv[: 4 * S].clone()
+        q2[:, 2 * heads * 64:] *= mag                              # v: the output scales with it
+        o = _value(ops.attention(q2, 4, S, heads, split=True, two_plane=True, three_products=True))
+        r = _attention_f64(q2, 4, S, heads)
+        assert float((o - r).abs().max() / r.abs().max()) < 5e-6, mag
+    with pytest.raises(Exception, match="S=192"):
+        ops.attention(torch.zeros(2 * 192, 3 * 768, device=DEV), 2, 192, 12, split=True, two_plane=True, three_products=True)
+    with pytest.raises(Exception, match="causal"):
+        ops.attention(torch.zeros(2 * 197, 3 * 768, device=DEV), 2, 197, 12, causal=True, split=True, two_plane=True, three_products=True)
 
 
 @pytest.mark.parametrize("tag,dims", [("tiny", synth.TINY), ("vitb16", synth.VIT_B_16)])
@@ -361,6 +399,23 @@ def test_values_beyond_fp16_raise_instead_of_passing_silently(tiny_state_dict):
     with pytest.raises(_lib.FitclipHipError, match="fp16"):
         hot.check_range()
     assert not bool(torch.isfinite(out).all())                   # and loud in the values themselves
+
+
+def test_attention_operands_beyond_fp16_raise_too(vitb16_state_dict):
+    """q, k, v enter fp16 planes inside the attention kernel (ViT-B/16: the fused three-product attention): a QKV bias that pushes
+    them beyond 65504 raises FC_ERANGE as well."""
+    d = synth.VIT_B_16
+    frames = torch.from_numpy(synth.make_video(1, 2, d, seed=9)).reshape(-1, 3, d.image_resolution, d.image_resolution).to(DEV)
+    ok = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV)
+    ok.encode_image(frames)
+    ok.check_range()
+    sd = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v.clone()) for k, v in vitb16_state_dict.items()}
+    key = "visual.transformer.resblocks.2.attn.in_proj_bias"
+    sd[key] = sd[key] + 1.0e5
+    hot = build_clip(sd, precision="fp32x3", device=DEV)
+    hot.encode_image(frames)
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.check_range()
 
 
 def test_gemm_split2_race_screen():
