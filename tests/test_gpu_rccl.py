@@ -36,6 +36,7 @@ def test_every_collective_of_the_path_runs_on_rccl():
     for key in ("gather_f32", "gather_i32", "gather_many", "all_reduce_async", "broadcast_barrier"):
         assert out[key] is True, key
     assert out["evaluate"]["equal"], out["evaluate"]
+    assert out["evaluate"]["gather_batches_equal"] and out["gather_counts"] == [5], out["evaluate"]
     # every sum of a training step has a fixed order (no float atomics): with or without the collectives, two runs of the
     # same two steps end bitwise equal
     assert out["train"]["losses_rccl"] == out["train"]["losses_plain"], out["train"]

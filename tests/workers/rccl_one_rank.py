@@ -22,9 +22,9 @@ from fitclip_amd.retrieval import TextVideoRetrievalModule  # noqa: E402
 from fitclip_amd.training import TeacherStudentTrainer  # noqa: E402
 
 
-def evaluate(sd, d, video, ids):
+def evaluate(sd, d, video, ids, gather_batches=False):
     module = TextVideoRetrievalModule(ClipVideoTextEncoder(build_clip(sd, precision="fp32", device="cuda:0")),
-                                      init_temperature=0.05, n_total=len(video))
+                                      init_temperature=0.05, n_total=len(video), gather_batches=gather_batches)
     with torch.inference_mode():
         for s in range(0, len(video), 8):
             module.validation_step_end(module.validation_step({"video": video[s:s + 8], "text": {"input_ids": ids[s:s + 8]},
@@ -76,12 +76,16 @@ def main():
     video = torch.from_numpy(synth.make_video(24, 2, d, seed=9)).cuda()
     ids = torch.from_numpy(synth.make_text(24, d, seed=9)).cuda()
     with_rccl = evaluate(sd, d, video, ids)
+    # the reference's per-step gathered loss/val: the size exchange and the packed two-tensor gather of every eval batch on RCCL
+    gathered_rccl = evaluate(sd, d, video, ids, gather_batches=True)
+    out["gather_counts"] = D.all_gather_counts(5, device)
     losses_rccl, params_rccl = train(sd, student_sd, video[:8], ids[:8])
     os.environ["FITCLIP_FORCE_COLLECTIVES"] = "0"
     assert not D.collectives_active()
     without = evaluate(sd, d, video, ids)
     losses_plain, params_plain = train(sd, student_sd, video[:8], ids[:8])
-    out["evaluate"] = {"rccl": with_rccl, "plain": without, "equal": with_rccl == without}
+    out["evaluate"] = {"rccl": with_rccl, "plain": without, "equal": with_rccl == without,
+                       "gather_batches_equal": gathered_rccl == without}  # (one rank: the gathered batch IS the local batch)
     out["train"] = {"losses_rccl": losses_rccl, "losses_plain": losses_plain,
                     "max_param_delta": float((params_rccl - params_plain).abs().max())}
     dist.barrier()
