@@ -388,13 +388,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
             for (int gq = 0; gq < 4; ++gq) {
               f32x4 v = f32x4{acc[i][j][gq * 4], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]} * w_inv;
               v = quick_gelu_f32x4(v);  // (packed pairs; the bits of quick_gelu_exact)
-#if defined(FITCLIP_X2_EV) && FITCLIP_X2_EV == 1   // (tools/split2_lab only: the range check spelled as v_max3_f32 |.|)
-              asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
-              asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
-#elif defined(FITCLIP_X2_EV) && FITCLIP_X2_EV == 3  // (... and without the range check: what it costs)
-#else
               amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-#endif
               split2(v, h1[gq], h2[gq]);
             }
             const int group = (cn0 + wn * TN + j * 32) / X2_GROUP;                       // wave-uniform
