@@ -792,6 +792,7 @@ def main() -> None:
     ap.add_argument("--gemm-tile", type=int, default=0)
     ap.add_argument("--cpu-sample-clips", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--truth-clips", type=int, default=4, help="clips of the CPU sample also evaluated in float64 (0 = skip)")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the (untimed, N = 1 only) KD training-step measurement reported under `kd_training_step`")
     ap.add_argument("--no-plant", action="store_true", help="keep the purely random towers (chance-level retrieval)")
@@ -1090,6 +1091,27 @@ def main() -> None:
                 "video_max_abs": (ev16[:k].cpu() - ev_ref).abs().max().item(),
                 "text_max_abs": (et16[:k].cpu() - et_ref).abs().max().item(),
                 "ranks_identical": bool(torch.equal(r16.long(), ref_ranks.long()))}
+        # distance of every path to the TRUTH: the oracle evaluated in float64 on the first clips of the sample (the same
+        # check as tests/test_gpu_split2.py::test_mode_is_as_close_to_float64_as_fp32_arithmetic_itself, at the bench's size)
+        kt = min(args.truth_clips, k)
+        if kt > 0:
+            sd64 = {kk: (v.double() if v.is_floating_point() else v) for kk, v in sd_t.items()}
+            with torch.inference_mode():
+                t0 = time.perf_counter()
+                tv64, tt64 = O.forward(sd64, v_cpu[:kt].double(), {"input_ids": ids_cpu[:kt]})
+                truth_s = time.perf_counter() - t0
+
+            def dist64(e_v, e_t):
+                return {"video_max_abs": float((e_v[:kt].cpu().double() - tv64).abs().max()),
+                        "text_max_abs": float((e_t[:kt].cpu().double() - tt64).abs().max())}
+
+            truth = {"sample": f"first {kt} clips + texts of the sample, oracle in float64, {truth_s:.1f} s",
+                     "oracle_fp32": dist64(ev_ref, et_ref), "fp32": dist64(ev, et)}
+            if ev6 is not None:
+                truth[result["fp32_split_mode"]["precision"]] = dist64(ev6, et6)
+            if ev16 is not None:
+                truth["bf16"] = dist64(ev16, et16)
+            result["distance_to_float64"] = truth
         return True
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -374,6 +374,47 @@ def test_mode_is_as_close_to_float64_as_fp32_arithmetic_itself(vitb16_state_dict
     assert err["fp32x3"] <= 2.0 * max(err["oracle fp32"], err["fp32"]) + 5e-8, err
 
 
+def test_heavy_tailed_weights_keep_the_fp32_accuracy(vitb16_state_dict):
+    """Trained CLIP towers are not the benign synthetic init: a few residual channels carry activations in the hundreds, the
+    LayerNorm gains of those channels are large, and some MLP units saturate.  The same shape of trouble, planted: outlier
+    channels out of ln_pre and in out_proj / c_proj (a residual stream of several hundred), LayerNorm gains up to 12 and
+    offsets up to 3, a c_fc bias that drives units far into both GELU tails (|pre-activation| to 17), Q and K rows scaled so
+    that the softmax is peaked (largest probability of a row up to 0.98).  The per-tensor weight scales, the two planes and the
+    range flag must hold: as close to float64 as the fp32 paths."""
+    from oracle import clip_oracle as O
+    d = synth.VIT_B_16
+    rng = np.random.default_rng(11)
+    sd = {k: np.array(v, copy=True) for k, v in vitb16_state_dict.items()}
+    hot = rng.choice(d.vision_width, 6, replace=False)
+    sd["visual.ln_pre.weight"][hot] *= 80.0                      # a residual stream of 250..370 in six channels (measured on the oracle)
+    for layer in range(d.vision_layers):
+        pre = f"visual.transformer.resblocks.{layer}."
+        sd[pre + "attn.out_proj.weight"][hot[:3]] *= 25.0
+        sd[pre + "mlp.c_proj.weight"][hot[3:]] *= 25.0
+        for ln in ("ln_1", "ln_2"):
+            gain = np.ones(d.vision_width, np.float32)
+            gain[rng.choice(d.vision_width, 8, replace=False)] = rng.uniform(4.0, 12.0, 8).astype(np.float32)
+            gain[hot] = 0.05                                       # (what training does to the outlier channels)
+            sd[pre + ln + ".weight"] = sd[pre + ln + ".weight"] * gain
+            sd[pre + ln + ".bias"] = sd[pre + ln + ".bias"] + rng.uniform(-3.0, 3.0, d.vision_width).astype(np.float32) * (gain > 1)
+        sd[pre + "mlp.c_fc.bias"] = sd[pre + "mlp.c_fc.bias"] + rng.normal(0.0, 4.0, 4 * d.vision_width).astype(np.float32)
+        sd[pre + "attn.in_proj_weight"][: 2 * d.vision_width] *= 3.0
+    sd32 = O.to_torch(sd)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    video = torch.from_numpy(synth.make_video(3, 2, d, seed=78))
+    with torch.inference_mode():
+        truth = O.encode_video(sd64, video.double())
+        cpu32 = O.encode_video(sd32, video)
+    assert torch.isfinite(truth).all()
+    err = {"oracle fp32": float((cpu32.double() - truth).abs().max())}
+    for precision in ("fp32", "fp32x3"):
+        model = build_clip(sd, precision=precision, device=DEV)
+        err[precision] = float((ClipVideoTextEncoder(model).encode_video(video.to(DEV)).cpu().double() - truth).abs().max())
+        model.check_range()                                          # nothing left fp16's range
+    print("heavy-tailed weights, max |embedding - float64 truth|:", err)
+    assert err["fp32x3"] <= 2.0 * max(err["oracle fp32"], err["fp32"]) + 5e-8, err
+
+
 def test_values_beyond_fp16_raise_instead_of_passing_silently(tiny_state_dict):
     """Never silently wrong: (1) LayerNorm weights whose outputs could leave fp16's range are refused when the weights are
     packed; (2) an activation that overflows at run time raises FC_ERANGE from `check_range()` and from the NEXT encode call."""
