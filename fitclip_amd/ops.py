@@ -231,16 +231,22 @@ def gemm_split2(a2: torch.Tensor, w2: torch.Tensor, scale: torch.Tensor, bias: t
     """epilogue(A @ W^T) for x2 operands a2 [M, 2 K] (`split2`, LayerNorm / attention x2 outputs, a previous EPI_GELU_X2 GEMM) and
     (w2 [N, 2 K], scale) from `split2_weight`: three fp16 MFMA products per fp32 product, fp32 accumulate (fc_gemm_split2).
     EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X2 -> x2 rows [M, 2 N] of QuickGELU(A @ W^T + bias); EPI_RESID3_F32: `out`
-    (float32 [M, N]) += A @ W^T + bias, in place.  `cut` (tests): tile height - 0 = by tile count, 1 = 256 rows, 2 = 128 rows; the
+    (float32 [M, N]) += A @ W^T + bias, in place (the other two write into `out` when one is given).  `cut` (tests): tile height - 0 = by tile count, 1 = 256 rows, 2 = 128 rows; the
     result does not depend on it."""
     _dev(a2, "a2", torch.float16), _dev(w2, "w2", torch.float16), _dev(bias, "bias", torch.float32), _dev(scale, "scale", torch.float32)
     if a2.dim() != 2 or w2.dim() != 2 or a2.shape[1] != w2.shape[1] or a2.shape[1] % 64:
         raise ValueError(f"x2 operands need matching [rows, 2 K] shapes, got {tuple(a2.shape)} and {tuple(w2.shape)}")
     M, N, K = a2.shape[0], w2.shape[0], a2.shape[1] // 2
     if epilogue == EPI_GELU_X2:
-        out = _x2_empty(M, N, a2.device)
+        if out is None:
+            out = _x2_empty(M, N, a2.device)
+        elif out.shape != (M, 2 * N) or out.dtype != torch.float16 or out.stride(1) != 1:
+            raise ValueError("EPI_GELU_X2 writes x2 rows [M, 2 N] (float16)")
     elif epilogue == EPI_BIAS_F32:
-        out = torch.empty((M, N), dtype=torch.float32, device=a2.device)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a2.device)
+        elif out.shape != (M, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError("EPI_BIAS_F32 writes float32 [M, N]")
     elif epilogue == EPI_RESID3_F32:
         if out is None or out.shape != (M, N):
             raise ValueError("the residual epilogue accumulates into `out` [M, N]")
