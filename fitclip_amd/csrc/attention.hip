@@ -23,6 +23,8 @@ namespace fc {
 namespace {
 
 constexpr float kNegInf = -__builtin_inff();
+// 1 / sqrt(64) and log2 e in one factor on the Q fragments of the fp32 kernels that compute their softmax in the log2 domain
+constexpr float kQScaleLog2 = 0.125f * 1.4426950408889634f;
 
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 kernel (second generation; what the first profile asked for: the first kernel - V transposed through registers into
@@ -536,18 +538,39 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
   // are conflict-free).  V: pieces of 4 keys at a stride of 1024 + 64 bytes, rows unpermuted: the four lane groups of a
   // P.V operand read (keys 4 g + e: row e of four consecutive pieces) land in four different quarter-banks, and the whole
   // address is one lane-dependent base plus compile-time offsets.
+  // The source of a piece is a wave-uniform address (item base + blk * BK rows + 32 rows for the wave's second K / V piece) plus
+  // a per-lane offset that is the same in every block (row = 4 wave + lane / 16 and its chunk swizzle; rows 32 apart share the
+  // swizzle): two offsets (K, V) per block and a piece costs one 64-bit add + one global_load_lds - address arithmetic
+  // between MFMAs is not free on the fp32 pipe (see the softmax below).  Only the block that straddles S clamps its rows.
+  static_assert(NW * NPIECE == 2 * BK / 4 && NW * 4 == BK / 2, "piece j of a wave: K rows 4 wave .., + 32, then V rows likewise");
   auto stage = [&](int blk) {  // keys [blk * BK, blk * BK + BK): lane l of a 4-row piece -> row l >> 4, chunk l & 15
-    const int prow = lane >> 4, pch = lane & 15;
+    char* dst = smem + (blk & 1) * BUF;
+    if (blk * BK + BK <= S) {  // wave-uniform
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));  // (opaque: a dozen instructions per block instead of four registers through the kernel)
+      const int srow0 = wave * 4 + (lane_s >> 4);
+      const unsigned koff0 = (unsigned)((D + srow0 * (int)ld + (((lane_s & 15) ^ (srow0 & 15)) << 2)) * 4);
+      const unsigned voff0 = (unsigned)((2 * D + srow0 * (int)ld + ((lane_s & 15) << 2)) * 4);
+      const char* bbase = reinterpret_cast<const char*>(base + (long)blk * BK * ld);  // wave-uniform
+      long half = 32 * 4 * ld;  // bytes from a wave's first K / V piece to its second
+      asm volatile("" : "+s"(half));  // (a scalar add on the base, not a second pair of per-lane offsets)
 #pragma unroll
-    for (int j = 0; j < NPIECE; ++j) {
-      const int p = wave + j * NW;          // pieces 0..15: K, 16..31: V
-      if (p < 2 * BK / 4) {
-        const int isv = p >= BK / 4, piece = p - (isv ? BK / 4 : 0);
+      for (int j = 0; j < NPIECE; ++j) {
+        const int isv = j >> 1, piece = wave + (j & 1) * NW;  // pieces wave, wave + 8 of K, then of V
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bbase + (j & 1) * half + (isv ? voff0 : koff0)),
+                                         (__attribute__((address_space(3))) void*)(dst + (isv ? OFF_V + piece * VPIECE : piece * 1024)),
+                                         16, 0, 0);
+      }
+    } else {
+      const int prow = lane >> 4, pch = lane & 15;
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) {
+        const int isv = j >> 1, piece = wave + (j & 1) * NW;
         const int row = piece * 4 + prow;
         const int srow = min(blk * BK + row, S - 1);  // padded keys read a valid row; they are masked
         const float* src = base + (isv ? 2 * D : D) + (long)srow * ld + ((isv ? pch : pch ^ (row & 15)) << 2);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + (blk & 1) * BUF + (isv ? OFF_V + piece * VPIECE : piece * 1024)),
+                                         (__attribute__((address_space(3))) void*)(dst + (isv ? OFF_V + piece * VPIECE : piece * 1024)),
                                          16, 0, 0);
       }
     }
@@ -570,7 +593,7 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
     lrun[qi] = 0.f;
     const float* qrow = base + (long)min(qtile[qi] * 16 + r, S - 1) * ld + 4 * g;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qf[qi][c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c) * 0.125f;
+    for (int c = 0; c < 4; ++c) qf[qi][c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c) * kQScaleLog2;
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[qi][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -603,6 +626,11 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
           }
           sT[t] = acc;
         }
+        // softmax in the log2 domain (the scores carry log2 e / 8 from the Q fragments): p = 2^(s - max) is ONE v_exp_f32 on an
+        // exact difference.  VALU instructions do not hide under fp32 MFMAs (tools/mfma_f32_chain_lab: both run on the SIMD's
+        // fp32 lanes, every v_* between two MFMAs adds its 2 - 7 cycles to the 32 of the MFMA), so what counts here is their
+        // NUMBER: v_max3, packed subtract / add / multiply, no compensated exponential (its job - the rounding of s log2 e - is
+        // done by the scale of Q), masked scores are -inf and 2^-inf = 0 without a select.
         float mx = mrun[qi];
 #pragma unroll
         for (int t = 0; t < BT; ++t) {
@@ -611,24 +639,25 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
             for (int e = 0; e < 4; ++e)
               if (blk * BK + t * 16 + 4 * g + e >= S) sT[t][e] = kNegInf;
           }
-          mx = fmaxf(fmaxf(mx, fmaxf(sT[t][0], sT[t][1])), fmaxf(sT[t][2], sT[t][3]));
+          mx = fmaxf(fmaxf(mx, sT[t][0]), sT[t][1]);   // v_max3_f32
+          mx = fmaxf(fmaxf(mx, sT[t][2]), sT[t][3]);
         }
         mx = max_over_lane_groups(mx);            // finite from the first block on (key 0 is never masked)
-        const float alpha = exp_neg_f32(mrun[qi] - mx);  // exp(-inf) = 0 on the first block
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qi] - mx);  // 2^-inf = 0 on the first block
         mrun[qi] = mx;
-        float sum = 0.f;
+        f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < BT; ++t) {
-          if (blk * BK + t * 16 + 16 > S) {       // tiles with masked keys: the guarded exponential (exp(-inf) = 0)
+          const f32x2 lo = f32x2{sT[t][0], sT[t][1]} - mx, hi = f32x2{sT[t][2], sT[t][3]} - mx;  // v_pk_add_f32
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sT[t][e] = ABL == 1 ? sT[t][e] - mx : exp_neg_f32(sT[t][e] - mx);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sT[t][e] = ABL == 1 ? sT[t][e] - mx : exp_neg_finite_f32(sT[t][e] - mx);
+          for (int e = 0; e < 2; ++e) {
+            sT[t][e] = ABL == 1 ? lo[e] : __builtin_amdgcn_exp2f(lo[e]);
+            sT[t][2 + e] = ABL == 1 ? hi[e] : __builtin_amdgcn_exp2f(hi[e]);
           }
-          sum += (sT[t][0] + sT[t][1]) + (sT[t][2] + sT[t][3]);
+          sum2 += f32x2{sT[t][0], sT[t][1]};
+          sum2 += f32x2{sT[t][2], sT[t][3]};
         }
-        lrun[qi] = lrun[qi] * alpha + sum;        // per lane group; the four groups are added at the end
+        lrun[qi] = lrun[qi] * alpha + (sum2[0] + sum2[1]);  // per lane group; the four groups are added at the end
 #pragma unroll
         for (int n = 0; n < 4; ++n) o[qi][n] *= alpha;
 #pragma unroll
@@ -685,10 +714,12 @@ attn_f32_blocks_kernel(const float* __restrict__ qkv, float* __restrict__ out, i
   } else {
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
-      const int query = qtile[qi] * 16 + r;
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));  // (opaque: the output addresses are computed here, not kept in registers through the blocks)
+      const int query = qtile[qi] * 16 + (lane_o & 15);
       const float inv = 1.f / sum_over_lane_groups(lrun[qi]);
       if (query < S) {
-        float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * g;
+        float* orow = out + ((long)seq * S + query) * D + h * 64 + 4 * (lane_o >> 4);
 #pragma unroll
         for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(orow + 16 * n) = o[qi][n] * inv;
       }

@@ -60,6 +60,16 @@ __global__ void count_diff(const float* a, const float* b, size_t n, unsigned lo
   if (c) atomicAdd(cnt, c);
 }
 
+void compare(const float* a, const float* b, size_t n, const char* what) {
+  unsigned long long *cnt, host = 0;
+  HIP_OK(hipMalloc(&cnt, 8));
+  HIP_OK(hipMemset(cnt, 0, 8));
+  count_diff<<<1024, 256>>>(a, b, n, cnt);
+  HIP_OK(hipMemcpy(&host, cnt, 8, hipMemcpyDeviceToHost));
+  printf("       %-42s %llu of %zu values differ from the blocks kernel\n", what, host, n);
+  HIP_OK(hipFree(cnt));
+}
+
 int main(int argc, char** argv) {
   const int n_seq = argc > 1 ? atoi(argv[1]) : 1024, reps = argc > 2 ? atoi(argv[2]) : 10, S = 197, heads = 12;
   const size_t nq = (size_t)n_seq * S * 3 * heads * 64, no = nq / 3;
@@ -77,9 +87,9 @@ int main(int argc, char** argv) {
   run<4>(qkv, out, n_seq, S, heads, reps, "no staging, no barriers");
   run<5>(qkv, out, n_seq, S, heads, reps, "no P.V MFMAs (VALU stand-in)");
   run<6>(qkv, out, n_seq, S, heads, reps, "no S MFMAs (VALU stand-in)");
-  run<0, 7>(qkv, out, n_seq, S, heads, reps, "7 waves per workgroup (14 tile slots)");
   run<0>(qkv, out, n_seq, S, heads, reps, "product kernel (again)");
-  // (the persistent-workgroup form - bitwise equal, 6 % slower - was removed in round 5: profiles/r04_attn_persist_lab.log)
+  // (the persistent-workgroup form - bitwise equal, 6 % slower - was removed in round 5: profiles/r04_attn_persist_lab.log; so was
+  // the two-heads-per-workgroup form with software-pipelined tiles: profiles/r05_attn_pair_lab.log)
   run<0>(qkv, out, n_seq, S, heads, reps, "product kernel (again)");
   return 0;
 }
