@@ -205,7 +205,7 @@ def load_traffic(precision, shape, epilogue):
     from fitclip_amd.build import source_fingerprint
     fp = source_fingerprint()
     seen = []
-    for name in (f"traffic_r05_{precision}.json", f"traffic_r04_{precision}.json", f"traffic_r04_{precision}_c3.json", f"traffic_r03_{precision}.json",
+    for name in (f"traffic_r05_{precision}.json", f"traffic_r05_{precision}_c3.json", f"traffic_r04_{precision}.json", f"traffic_r04_{precision}_c3.json", f"traffic_r03_{precision}.json",
                  f"traffic_r02_{precision}.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.exists(path):
