@@ -151,6 +151,15 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       sq += s[i] * s[i];
     }
     const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / D) + 1e-5f);
+#ifdef FITCLIP_LAB
+    // (tools/ only, FITCLIP_LAB_LN_FUSE=1: what a statistics-only pass would cost - mean and 1 / std of the row, no normalised row)
+    if (y_stride < 0) {
+      if constexpr (std::is_same<OutT, float>::value) {
+        if (lane == 0) *reinterpret_cast<f32x2*>(y + (long)row * -y_stride) = f32x2{mean, rstd};
+      }
+      continue;
+    }
+#endif
     OutT* yr = y + (long)row * y_stride;
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
