@@ -287,14 +287,22 @@ static bool lab_skip_ln() {
 }
 // FITCLIP_LAB_LN_FUSE=1: what the algebraic LayerNorm fusion would cost with a statistics-only pass in place of every block
 // LayerNorm (mean, 1 / std per row; no normalised row) and the correction rstd (acc - mean g) + c in the QKV / c_fc epilogues
-// (gemm_kernel.h, on stand-in vectors): results meaningless, timing valid (tools/ln_ceiling.py)
+// (gemm_kernel.h, on stand-in vectors; the switch travels in GemmArgs::P, which these epilogues do not use): results
+// meaningless, timing valid (tools/ln_ceiling.py)
 static bool lab_ln_fuse() {
   static const bool v = [] { const char* e = getenv("FITCLIP_LAB_LN_FUSE"); return e && atoi(e) != 0; }();
+  return v;
+}
+// FITCLIP_LAB_GELU=2: the c_fc epilogue without its QuickGELU (what the function costs in place); 3: the plain form
+// x / (1 + 2^(-1.702 log2 e x)) without the compensated exponent (what dropping the compensation would buy)
+static int lab_gelu() {
+  static const int v = [] { const char* e = getenv("FITCLIP_LAB_GELU"); return e ? atoi(e) : 0; }();
   return v;
 }
 #else
 static constexpr bool lab_skip_ln() { return false; }
 static constexpr bool lab_ln_fuse() { return false; }
+static constexpr int lab_gelu() { return 0; }
 #endif
 
 int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal,
@@ -316,7 +324,7 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
       ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, lab_ln_fuse() && kind == 0 ? -w : w, kind, M, w, st));
     }
-    FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, lab_ln_fuse() && kind == 0 && l > 0 ? reinterpret_cast<const float*>(s.xn) : nullptr, M, 3 * w, w, 3 * w, 0, st));
+    FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, lab_ln_fuse() && kind == 0 && l > 0 ? 1 : 0, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
       FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
@@ -341,7 +349,7 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
       ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln2_w, b.ln2_b, s.xn, lab_ln_fuse() && kind == 0 && l > 0 ? -w : w, kind, M, w, st));
     }
-    FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, lab_ln_fuse() && kind == 0 && l > 0 ? reinterpret_cast<const float*>(s.xn) : nullptr, M, 4 * w, w, 4 * w, 0, st));
+    FC_TRY(gemm(h, EPI_GELU_T, s.xn, b.fc_w, b.fc_b, s.big, nullptr, M, 4 * w, w, 4 * w, kind == 0 ? (lab_ln_fuse() && l > 0 ? 1 : lab_gelu()) : 0, st));
     FC_TRY(gemm(h, EPI_RESID_F32, s.big, b.proj_w, b.proj_b, s.x, nullptr, M, w, 4 * w, w, 0, st));
   }
   return launch_layernorm(s.x, xs_pool, pool_idx, fin_w, fin_b, s.clsn, w, kind, n_seq, w, st);

@@ -927,10 +927,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
               const int n = cn0 + wn * TN + j * 16 + 4 * q;
               f32x4 v = acc[i][j];
 #ifdef FITCLIP_LAB
-              // (tools/ only, FITCLIP_LAB_LN_FUSE=1 -> g.aux set: the epilogue correction of an algebraic LayerNorm fusion,
-              // rstd (acc - mean g) + c, on stand-in vectors out of the bias slice in LDS - what it would COST; api.hip)
+              // (tools/ only; the switch is GemmArgs::P, unused by these epilogues - api.hip.  1: the epilogue correction of an
+              // algebraic LayerNorm fusion, rstd (acc - mean g) + c, on stand-in vectors out of the bias slice in LDS - what it
+              // would COST; 2: no QuickGELU; 3: the plain QuickGELU, no compensated exponent)
               if constexpr (EPI == EPI_BIAS_T || EPI == EPI_GELU_T) {
-                if (g.aux) {
+                if (g.P == 1) {
                   const float* sl = reinterpret_cast<const float*>(smem + OFF_BIAS + (it & 1) * 1024);
                   const float mu = sl[(i * 16 + r) & 255] * 1e-3f, rs = 1.f + sl[(i * 16 + r + 64) & 255] * 1e-3f;
                   const f32x4 gv = *reinterpret_cast<const f32x4*>(sl + wn * TN + j * 16 + 4 * q);
@@ -939,10 +940,19 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_pipelined_kernel(const Gemm
                   for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rs, __builtin_fmaf(-mu, gv[e], v[e]), cv[e]);
                 }
               }
-#endif
+              if constexpr (EPI == EPI_GELU_T) {
+                if (g.P == 3) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -2.4554669857025146f));
+                } else if (g.P != 2) {
+                  v = quick_gelu_f32x4(v);
+                }
+              }
+#else
               if constexpr (EPI == EPI_GELU_T) {
                 v = quick_gelu_f32x4(v);  // (packed pairs; the bits of quick_gelu_exact)
               }
+#endif
               if constexpr (EPI == EPI_DGELU_T) {
                 // (these loads make hipcc drain vmcnt before the stores; the counted wait of the next tile stays valid,
                 // it only asks for "at most NST operations still in flight")
