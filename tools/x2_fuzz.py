@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Random-shape screen of the two kernels of precision "fp32x3" (GPU): `fc_gemm_split2` over random (M, N, K, epilogue, tile height)
-and the three-product attention over random (sequences, S in 193..208, heads), every element against the fp32-MFMA kernels of the
-same operands, guard rows / columns around every output, and a second run for bit-equality.  The parity tests
+and the three-product attention over random (sequences, S in 193..208, heads), every element against FLOAT64 (rocBLAS dgemm / a float64 softmax of
+the same operands) next to the fp32-MFMA kernels' own error, guard rows / columns around every output, and a second run for bit-equality.  The parity tests
 (tests/test_gpu_split2.py) pin chosen shapes; this looks for the shape nobody chose.
 
     python tools/x2_fuzz.py [--cases 150] [--seed 0]      ->  one line per case, a summary line, exit code 1 on any failure"""
@@ -37,32 +37,36 @@ def gemm_case(rng, i):
     a2 = ops.split2(a)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     z32 = ops.gemm(a, w, bias, ops.EPI_BIAS_T)
-    mag = float(z32.abs().max()) + 1e-30
+    z64 = torch.addmm(bias.double(), a.double(), w.double().T)          # the truth (rocBLAS dgemm of the same fp32 operands)
+    mag = float(z64.abs().max()) + 1e-30
+    e32 = float((z32.double() - z64).abs().max()) / mag                 # what the fp32-MFMA kernel makes of them
     pad = 5                                                  # guard rows behind the output
     ok, detail = True, ""
     for run in range(2):
         if epi == "gelu":
             buf = torch.full((M + pad, 2 * N), GUARD, device=DEV, dtype=torch.float16)
             ops.gemm_split2(a2, w2, sc, bias, ops.EPI_GELU_X2, out=buf[:M], cut=cut, flag=flag)
-            got, want = value(buf[:M]), z32 * torch.sigmoid(1.702 * z32)
+            got, want = value(buf[:M]), z64 * torch.sigmoid(1.702 * z64)
         else:
             buf = torch.full((M + pad, N), GUARD, device=DEV)
             if epi == "resid":
                 x = torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7 + i)) * 3
                 buf[:M] = x
                 ops.gemm_split2(a2, w2, sc, bias, ops.EPI_RESID3_F32, out=buf[:M], cut=cut)
-                got, want = buf[:M], x + z32
+                got, want = buf[:M], x.double() + z64
             else:
                 ops.gemm_split2(a2, w2, sc, bias, ops.EPI_BIAS_F32, out=buf[:M], cut=cut)
-                got, want = buf[:M], z32
+                got, want = buf[:M], z64
         err = float((got.double() - want.double()).abs().max()) / mag
         guards = bool((buf[M:].float() == GUARD).all())
         if run == 0:
             first, first_err = got.clone(), err
         else:
             same = bool(torch.equal(got, first))
-            ok = first_err < 8e-6 and guards and same
-            detail = f"err {first_err:.1e} guards {guards} rerun-equal {same} flag {int(flag)}"
+            # as accurate as the fp32-MFMA kernel on the same operands (the x2 rows of the QuickGELU output hold 22 bits: + 2.4e-7)
+            slack = 4e-7 if epi == "gelu" else 1e-7 + (1.2e-7 * float(want.abs().max()) / mag if epi == "resid" else 0.0)  # (+ the rounding of x + z)
+            ok = first_err < 1.5 * e32 + slack and guards and same
+            detail = f"err {first_err:.1e} (fp32-MFMA kernel {e32:.1e}) guards {guards} rerun-equal {same} flag {int(flag)}"
     return ok, f"gemm  M={M:6d} N={N:5d} K={K:5d} {epi:5s} cut={cut}  {detail}"
 
 
@@ -73,13 +77,18 @@ def attention_case(rng, i):
     g = torch.Generator(device=DEV).manual_seed(5000 + i)
     qkv = torch.randn(n_seq * S, 3 * heads * 64, device=DEV, generator=g) * float(10.0 ** rng.uniform(-1, 0.5))
     o32 = ops.attention(qkv, n_seq, S, heads)
-    mag = float(o32.abs().max()) + 1e-30
+    D = heads * 64
+    q, k, v = (t.double().view(n_seq, S, heads, 64).transpose(1, 2) for t in qkv.split(D, dim=1))
+    o64 = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(n_seq * S, D)
+    mag = float(o64.abs().max()) + 1e-30
+    e32 = float((o32.double() - o64).abs().max()) / mag
     a = ops.attention(qkv, n_seq, S, heads, split=True, two_plane=True, three_products=True)
     b = ops.attention(qkv, n_seq, S, heads, split=True, two_plane=True, three_products=True)
-    err = float((value(a).double() - o32.double()).abs().max()) / mag
+    err = float((value(a).double() - o64).abs().max()) / mag
     same = bool(torch.equal(a, b))
     finite = bool(torch.isfinite(a.float()).all())
-    return err < 1.2e-5 and same and finite, f"attn  n_seq={n_seq:4d} S={S} heads={heads:2d}  err {err:.1e} rerun-equal {same} finite {finite}"
+    return (err < 1.5 * e32 + 4e-7 and same and finite,
+            f"attn  n_seq={n_seq:4d} S={S} heads={heads:2d}  err {err:.1e} (fp32-MFMA kernel {e32:.1e}) rerun-equal {same} finite {finite}")
 
 
 def main():
