@@ -38,6 +38,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr float kCross = 1.f / X2_RESID_SCALE;   // 2^-11
+// 1 / sqrt(64) and log2 e in one factor on Q before it is split: the scores come out in the log2 domain and a probability is ONE
+// v_exp_f32 of an exact difference (the compensated exponential of rounds 3-4 spent 7 packed operations per pair on the rounding of
+// s log2 e, which the scale of Q now carries; vector instructions are what bounds this kernel next to its HBM traffic)
+constexpr float kQLog2 = 0.125f * 1.4426950408889634f;
 
 // two values -> (h1 pair, h2 pair) as packed words: v_cvt_pk_f16_f32, two conversions back, one packed subtract, one packed
 // multiply, v_cvt_pk_f16_f32 - 6 VALU instructions per pair
@@ -156,11 +160,11 @@ struct Tile16h {
       qraw[s][1] = *reinterpret_cast<const f32x4*>(qrow + 32 * s + 4);
     }
   }
-  __device__ __forceinline__ void split_q(Ctx2& c) {  // pre-scaled by 1 / sqrt(64) (exact)
+  __device__ __forceinline__ void split_q(Ctx2& c) {  // pre-scaled by log2 e / sqrt(64): the softmax runs in the log2 domain
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       amax8(c.amax, qraw[s][0], qraw[s][1]);
-      split2x8(qraw[s][0] * 0.125f, qraw[s][1] * 0.125f, qf[0][s], qf[1][s]);
+      split2x8(qraw[s][0] * kQLog2, qraw[s][1] * kQLog2, qf[0][s], qf[1][s]);
     }
   }
   __device__ __forceinline__ void scores(const Ctx2& c) {
@@ -203,15 +207,15 @@ struct Tile16h {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const f32x2 x = f32x2{sT[t][2 * hh], sT[t][2 * hh + 1]} - m2;
-        const f32x2 pr = F::kNoExp ? x : exp_neg_finite_pair(x);
+        const f32x2 pr = F::kNoExp ? x : f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
         sT[t][2 * hh] = pr[0];
         sT[t][2 * hh + 1] = pr[1];
         sum2 += pr;
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {  // the guarded exponential: exp(-inf) = 0
-      const float pr = F::kNoExp ? 0.f : exp_neg_f32(sT[NKT - 1][e] - mx);
+    for (int e = 0; e < 4; ++e) {  // (masked keys: 2^-inf = 0)
+      const float pr = F::kNoExp ? 0.f : __builtin_amdgcn_exp2f(sT[NKT - 1][e] - mx);
       sT[NKT - 1][e] = pr;
       sum2[e & 1] += pr;
     }
@@ -300,11 +304,11 @@ struct Tile32h {
       qraw[ks][1] = *reinterpret_cast<const f32x4*>(qrow + 16 * ks + 4);
     }
   }
-  __device__ __forceinline__ void split_q(Ctx2& x) {  // pre-scaled by 1 / sqrt(64) (exact)
+  __device__ __forceinline__ void split_q(Ctx2& x) {  // pre-scaled by log2 e / sqrt(64): the softmax runs in the log2 domain
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       amax8(x.amax, qraw[ks][0], qraw[ks][1]);
-      split2x8(qraw[ks][0] * 0.125f, qraw[ks][1] * 0.125f, qf[0][ks], qf[1][ks]);
+      split2x8(qraw[ks][0] * kQLog2, qraw[ks][1] * kQLog2, qf[0][ks], qf[1][ks]);
     }
   }
   __device__ __forceinline__ void scores(const Ctx2& x) {
@@ -358,7 +362,7 @@ struct Tile32h {
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         const f32x2 xx = f32x2{sT[T][e], sT[T][e + 1]} - m2;
-        const f32x2 pr = F::kNoExp ? xx : exp_neg_finite_pair(xx);
+        const f32x2 pr = F::kNoExp ? xx : f32x2{__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
         sT[T][e] = pr[0];
         sT[T][e + 1] = pr[1];
         sum2 += pr;
@@ -370,8 +374,8 @@ struct Tile32h {
                  f32x4{sT[T][8 * i + 4], sT[T][8 * i + 5], sT[T][8 * i + 6], sT[T][8 * i + 7]}, pl[T][i][0], pl[T][i][1]);
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {  // the guarded exponential (exp(-inf) = 0); keys 208 .. 223 are P = 0 outright
-      const float pr = e < 8 && !F::kNoExp ? exp_neg_f32(sT[NT32 - 1][e] - mx) : 0.f;
+    for (int e = 0; e < 16; ++e) {  // (masked keys: 2^-inf = 0); keys 208 .. 223 are P = 0 outright
+      const float pr = e < 8 && !F::kNoExp ? __builtin_amdgcn_exp2f(sT[NT32 - 1][e] - mx) : 0.f;
       sT[NT32 - 1][e] = pr;
       sum2[e & 1] += pr;
     }
