@@ -6,6 +6,8 @@
 //     that basis (attention.hip), and no arrangement of it (software pipelining inside a wave, more waves) can hide it.
 //   * v_mfma_f32_16x16x32_f16 (an XDL operation, 16 cycles): the MFMA holds the vector issue for 8 of its 16 cycles (the rule of
 //     MI355X_MICROARCH.md): two v_fma_f32 per MFMA fit, four or eight add up (8 + 4 n cycles per MFMA).
+//   * no MFMA at all (two or four waves per SIMD): v_fma_f32 2.7 cycles, v_pk_mul_f32 / v_max3_f32 / v_cvt_pkrtz 4.3 (per element the
+//     packed forms win by a fifth - in a vector-only phase such as an epilogue; beside MFMAs they do not), v_exp_f32 8.2.
 // Both sides are volatile asm: left to the scheduler, hipcc moves all vector instructions behind the 64 MFMAs of the loop body
 // (sched_group_barrier or not) and the waves of a SIMD then run their two phases in lock step, which measures something else.
 // Also: the dependence pattern (CHAIN accumulators in rotation; 1 = every MFMA takes the previous one's result) does not matter.
@@ -41,6 +43,7 @@ __global__ void __launch_bounds__(1024) chain_kernel(float* out, int iters, long
       // volatile asm on both sides: the instruction stream IS this order (left to the scheduler, hipcc moves all the VALU
       // instructions behind the 64 MFMAs, sched_group_barrier or not, and the waves of a SIMD then run their phases in lock step)
       if (MF == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[k % CHAIN]) : "v"(a), "v"(b));
+      else if (MF == 2) {}  // no MFMA: the vector instructions alone
       else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[k % CHAIN]) : "v"(ha), "v"(hb));
 #pragma unroll
       for (int j = 0; j < VALU; ++j) {
@@ -84,7 +87,7 @@ void run(float* out, long long* cyc, int threads, const char* what) {
   HIP_OK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
   const double mfma_per_simd = (double)iters * 64 * (threads / 256);
   // s_memtime / readcyclecounter ticks at 100 MHz on gfx9: use the wall time and report ns per MFMA and SIMD; at 2.4 GHz 32 cycles = 13.3 ns
-  printf("%s chain %2d  valu %d  %d waves/SIMD  %-28s %7.2f ns per MFMA and SIMD  (%.1f cycles at 2.4 GHz)  [%lld ticks]\n", MF ? "f16 16x16x32" : "f32 16x16x4 ", CHAIN, VALU,
+  printf("%s chain %2d  valu %d  %d waves/SIMD  %-28s %7.2f ns per MFMA and SIMD  (%.1f cycles at 2.4 GHz)  [%lld ticks]\n", MF == 2 ? "no MFMA     " : MF ? "f16 16x16x32" : "f32 16x16x4 ", CHAIN, VALU,
          threads / 256, what, best * 1e6 / mfma_per_simd, best * 1e6 / mfma_per_simd * 2.4, c);
 }
 
@@ -113,6 +116,13 @@ int main() {
     run<4, 4, 6, 1>(out, cyc, threads, "+ 4 v_pk_mul_f32 (independent)");
     run<4, 4, 6, 0>(out, cyc, threads, "+ 4 v_pk_mul_f32 (independent)");
     run<4, 4, 7, 1>(out, cyc, threads, "+ 4 v_cvt_pk_f16_f32 (v_cvt_pkrtz)");
+    run<4, 8, 1, 2>(out, cyc, threads, "8 independent v_fma");
+    run<4, 8, 6, 2>(out, cyc, threads, "8 v_pk_mul_f32 (independent)");
+    run<4, 8, 3, 2>(out, cyc, threads, "8 v_pk_mul_f32 (chained)");
+    run<4, 8, 0, 2>(out, cyc, threads, "8 chained v_fma");
+    run<4, 8, 2, 2>(out, cyc, threads, "8 v_exp_f32");
+    run<4, 8, 4, 2>(out, cyc, threads, "8 v_max3_f32");
+    run<4, 8, 7, 2>(out, cyc, threads, "8 v_cvt_pkrtz_f16_f32");
   }
   return 0;
 }
