@@ -155,7 +155,11 @@ def _attention_ref(qkv, n, S, heads, causal):
                                               # > 224 tokens: the streaming kernel (ViT-L/14: 257, @336px: 577) and
                                               # tile-boundary cases of its 64-key ring / 16-query tiles
                                               (2, 257, 16, False), (1, 577, 3, False), (2, 225, 1, False),
-                                              (1, 256, 2, False), (1, 320, 1, False), (1, 321, 2, False)])
+                                              (1, 256, 2, False), (1, 320, 1, False), (1, 321, 2, False),
+                                              # the streaming-block kernel of 97..224 tokens (log2-domain softmax, round 5) at the ends of
+                                              # its range, at whole and ragged key blocks of 64 and with the last block almost empty
+                                              (2, 97, 2, False), (3, 113, 3, False), (2, 128, 12, False), (2, 129, 4, False),
+                                              (2, 192, 2, False), (3, 193, 12, False), (2, 208, 1, False), (2, 209, 3, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention(n, S, heads, causal, dtype):
     qkv = _rand(n * S, 3 * heads * 64, seed=S)
