@@ -6,60 +6,79 @@
 //
 //   x = h1 + 2^-11 h2,  s w = g1 + g2      =>      x (s w) = h1 g1 + h1 g2 + h2 (2^-11 g1)     (+ 2^-22: the dropped h2 g2)
 //
-// Kernel: 256 x 256 output tile per workgroup of 8 waves (2 x 4; wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32), persistent
-// (one workgroup per CU), v_mfma_f32_32x32x16_f16.  A K-step is one line of every operand row = 32 columns = TWO k-halves of
-// 16; its 48 MFMAs per wave are issued in 8 groups (k-half, 32-row tile) of 6: [g1 h1, g2 h1, (2^-11 g1) h2] x 2 column tiles.
-// LDS: TWO stages of 64 KiB - [512 tile rows][128 B], the image, chunk swizzle (physical chunk pc of row r holds logical chunk
-// pc ^ (r >> 1 & 7), applied on the source side of the LDS-DMA) and staging code of gemm_pipelined_kernel (gemm_kernel.h) - plus
-// a 2 KiB output patch per wave and the bias slices, 146 KiB.  The fragments of a k-half live in registers for that k-half only
-// (weights 2 planes x 2 column tiles + the scaled copy, activations 2 planes of the current and the next row tile): 56 fragment
-// registers next to 128 accumulators.  Structure of the K loop as in gemm_pipelined_kernel: LDS reads of group u + 1 in front of
-// the MFMAs of group u, the hand-over (counted vmcnt, raw s_barrier, LDS-DMA of K-step kt + 2, first fragments of K-step kt + 1)
-// in front of the LAST group, the next tile's first two K-steps requested before the epilogue stores.
-// Epilogues: a 32 x 32 tile leaves through the wave's 16-row x 128-byte patch in two half passes (the lanes of rows 0..15, then
-// of rows 16..31 write; all lanes read back 8 rows x 128 contiguous bytes per store instruction): fp32 rows, fp32 rows added to C
-// in place (the residual stream), or exact QuickGELU + x2 rows (a 32 x 32 tile is exactly one 128-byte line of 32 rows).
+// Kernel: 256 x 256 output tile per workgroup of 8 waves (2 x 4; wave tile 128 x 64 = 8 x 4 MFMA tiles of 16 x 16), persistent
+// (one workgroup per CU), v_mfma_f32_16x16x32_f16.  Round 5 shipped this kernel on the 32x32x16 shape (tools/gemm_split2_m32.h,
+// kept for the lab): it ran at the chip's power limit, and at that limit the chip holds a higher clock on the 16x16x32 shape at
+// equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7) - the bare MFMA + LDS-read loop of this kernel reaches
+// 0.70 - 0.71 of the fp16 peak where the 32x32x16 loop reached 0.61 - 0.62, the whole kernel 7 - 9 % less time on the four block
+// shapes (tools/x2k_lab, docs/rounds/round6.md).  One MFMA covers the whole K-depth of a 128-byte line (32 columns):
+//   * a K-step = one line of every operand row = ONE k-slice; its 96 MFMAs per wave are issued in 8 groups (one 16-row tile each)
+//     of 12: g1 h1 x 4 column tiles, g2 h1 x 4, (2^-11 g1) h2 x 4 - consecutive MFMAs hit different accumulators;
+//   * fragments: lane (r = lane & 15, q = lane >> 4) reads the 16 bytes k = 8 q .. 8 q + 7 of plane p of tile row r: logical chunk
+//     4 p + q (conflict-free under the image's chunk swizzle: the 16 lanes of a ds_read_b128 group touch 16 distinct bank slots);
+//   * the weight fragments of a K-step (g1, g2 and the scaled copy of g1 for four column tiles: 48 registers) stay in registers
+//     for all 8 groups; they are replaced IN the last group, plane by plane, each as soon as its four MFMAs have been issued (the
+//     hand-over barrier in front of that group has published the next K-step); activations: two planes of the current and of the
+//     next row tile (16 registers) next to 128 accumulators;
+//   * LDS: two stages per operand, [activation rows, stage 0 | 1 | weight rows, stage 0 | 1], 128 bytes per tile row with the
+//     chunk swizzle of gemm_pipelined_kernel (physical chunk pc of row r holds logical chunk pc ^ (r >> 1 & 7), applied on the
+//     source side of the LDS-DMA), plus a 2 KiB output patch per wave and the bias slices: 146 KiB;
+//   * LDS-DMA through buffer descriptors rebuilt per tile from scalars (rows beyond M / N fail the range check instead of being
+//     clamped per lane), the pieces of K-step kt + 1 issued behind the first MFMA groups of K-step kt, the hand-over (counted
+//     vmcnt, raw s_barrier) in front of the LAST group, the next tile's first two K-steps requested before the epilogue stores;
+//   * epilogues: a lane of a 16 x 16 tile holds four consecutive columns of one row, two column tiles are one 128-byte line of
+//     16 rows = the wave's patch: all lanes write, all lanes read back 8 rows x 128 contiguous bytes per store instruction:
+//     fp32 rows, fp32 rows added to C in place (the residual stream), or exact QuickGELU + x2 rows.
+// An output element sees one chain of 16x16x32 products in an order that only depends on its column tile: rows are bit-invariant
+// to the batch, the tile height and the launch geometry.
 #pragma once
 #include "gemm_kernel.h"
 
 namespace fc {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// issue slot of LDS-DMA piece idx (0..3 activation rows, 4..7 weight rows) of a wave: -1 = in the hand-over (a whole K-step
+// issue slot of LDS-DMA piece idx (0..lpa-1 activation rows, then weight rows) of a wave: -1 = in the hand-over (a whole K-step
 // before its data is needed), u >= 0 = behind MFMA group u of the NEXT K-step (the stage was released by the hand-over barrier in
-// front of that step; the piece must land before group 7 of the same step waits for it, so only the first half is used)
+// front of that step; the piece must land before the last group of the same step waits for it, so only the first half is used)
 constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
   switch (spread) {
-    case 1: return idx < lpa ? -1 : 0;    // A in the hand-over, W behind group 0
-    case 2: return idx / 2 - 1;           // 2 in the hand-over, 2 behind each of groups 0, 1, 2
-    case 3: return idx / 2;               // 2 behind each of groups 0..3 (128-row tiles, 6 pieces: groups 0..2 of their 4)
-    case 4: return idx < lpa ? -1 : (idx - lpa) / 2;  // A in the hand-over, W behind groups 0, 1
+    case 1: return idx < lpa ? -1 : 0;
+    case 2: return idx / 2 - 1;
+    case 3: return idx / 2;
+    case 4: return idx < lpa ? -1 : (idx - lpa) / 2;
+    case 5: return idx / 3;               // 3, 3, 2 behind groups 0, 1, 2
+    case 6: return idx / 4;               // 4 behind each of groups 0, 1
     default: return -1;
   }
 }
 
-// ABL (tools/split2_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 2 = every workgroup stages the operand rows
-// of tile (0, 0) (all loads hit L2); 3 = no epilogue; 6 = no loads, no waits, no epilogue (MFMA + LDS reads only)
-// RW: residual rows requested RW tiles ahead (EPI_RESID3_F32); RR: tiles dealt round robin instead of the XCD panel ranges
-// BMT = 128: tiles of 128 rows (wave tile 64 x 64, half the MFMAs per K-step for the same weight tile: less efficient per FLOP) for
-// the TAIL of a launch whose 256-row tiles would not fill whole rounds over the compute units (gemm_split2.hip: plan).  An output
-// element sees the same K order and the same chain of 32 x 32 x 16 products whatever the tile height: bit-identical rows.
-template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 2, int RR = 0, int BMT = 256>
+// ABL (tools/x2k_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 3 = no epilogue; 6 = no loads, no waits, no
+// epilogue (MFMA + LDS reads only); 4 = the real kernel with s_memtime stamps around the hand-over wait, the hand-over barrier, the
+// K loop and the epilogue, summed per wave into g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).  RW: residual rows requested RW patches (16 rows x 32 columns) ahead (EPI_RESID3_F32).
+// PF: activation fragments requested PF row tiles ahead (2: three register sets, 256-row tiles only)
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1>
 __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   constexpr int BM = BMT, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 (64) x 64 per wave
-  constexpr int FM = TM / 32, FN = TN / 32;        // 4 (2) x 2 MFMA tiles of 32 x 32
-  constexpr int NG = 2 * FM;                       // MFMA groups per K-step: (k-half, row tile)
-  constexpr int STAGE = (BM + BN) * ROWB;          // 65536 (49152)
+  constexpr int FM = TM / 16, FN = TN / 16;        // 8 (4) x 4 MFMA tiles of 16 x 16
+  constexpr int NG = FM;                           // MFMA groups per K-step: one per row tile
+  // LDS: [activation rows, stage 0 | stage 1 | weight rows, stage 0 | stage 1 | patches | bias]: the two stages of an operand lie
+  // BM (BN) x 128 bytes apart, so ONE address register per operand and plane reaches every fragment of both stages through the
+  // 16-bit immediate of ds_read_b128 (stages 64 KiB apart took one register per row tile and stage: 24 address registers)
+  constexpr int STG_A = BM * ROWB, STG_W = BN * ROWB;   // 32768 (16384), 32768
+  constexpr int OFF_W = 2 * STG_A;
+  constexpr int STAGE = STG_A + STG_W;             // bytes per stage: 65536 (49152)
   constexpr int LPA = BM / 8 / NW, LPB = BN / 8 / NW, LPW = LPA + LPB;  // LDS-DMA pieces per wave and stage: 4 (2) + 4
   static_assert(BM == 256 || BM == 128, "tile height");
+  static_assert(FN == 4 && NG % 2 == 0, "wave tile");
+  static_assert(PF == 1 || (PF == 2 && NG == 8), "prefetch distance");
+  constexpr int NAF = PF + 1;                      // activation fragment sets: row tile i lives in set i % NAF
   constexpr int OFF_STG = 2 * STAGE;               // 8 patches of 2 KiB
   constexpr int OFF_BIAS = OFF_STG + NW * 2048;    // 2 x 1 KiB
   constexpr bool kOutX2 = EPI == EPI_GELU_X2;
   constexpr bool kResid = EPI == EPI_RESID3_F32;   // C += acc + bias (fp32, in place)
-  constexpr int NST = FM * FN * 4;                 // store instructions per wave and interior tile (32: x2 rows are 4 B per value too)
+  constexpr int NP = FM * (FN / 2);                // patches (16 rows x 32 columns) per wave and tile: 16 (8)
+  constexpr int NST = NP * 2;                      // store instructions per wave and interior tile: 32 (16)
   static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X2 || EPI == EPI_RESID3_F32, "epilogue");
   static_assert(LPW + NST < 64, "the counted wait behind the epilogue stores must fit the 6-bit vmcnt");
 
@@ -68,8 +87,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- tile schedule (gemm_split3_kernel's): XCD x (= blockIdx & 7) owns a contiguous range of M-panels (optionally only
-  // 1 / nsplit of the N range); its workgroups stride through that range in N-fastest order
+  // ---- tile schedule (gemm_split2_kernel's)
   const int tilesN = (g.N + BN - 1) / BN;
   const int tilesM = (g.M + BM - 1) / BM;
   const int G = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
@@ -89,82 +107,79 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   const int nk = g.K / X2_GROUP;                   // K-steps: one 128-byte line of every operand row each (even, >= 4)
   const unsigned lda_b = (unsigned)g.lda * 2u, ldw_b = (unsigned)g.ldw * 2u;  // row strides in bytes (lda / ldw count fp16)
   const float w_s = g.wscale[0], w_inv = g.wscale[1];
-  // K-steps of a tile are visited in a rotated order that only depends on the column tile (gemm_split3_kernel: neighbouring
-  // column tiles one K-step apart), so a row's result does not depend on the rows around it
+  // LDS-DMA sources through two buffer descriptors (activation rows / weight rows of the CURRENT tile, rebuilt per tile from
+  // scalars): a lane's address is [descriptor base] + [its row and swizzled chunk: ONE 32-bit register per operand, the same for
+  // every tile] + [piece: 64 rows, a scalar] + [K-step: a scalar], and rows beyond M / N fail the descriptor's range check (their
+  // lanes fetch nothing) instead of being clamped lane by lane.  With 64-bit global addresses hipcc kept a register PAIR per
+  // activation piece and a register per weight piece alive across the K loop: 12 registers, here 2.
   int rot = 0;
-  unsigned offA[LPA], offB[LPB];
-  const char* a_tile = reinterpret_cast<const char*>(g.A);  // 64-bit base of the current tile's first activation row (scalar)
+  unsigned offA0, offB0;
+  {
+    const int rin = lane >> 3, pc = lane & 7;
+    const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
+    offA0 = (unsigned)(wave * 8 + rin) * lda_b + swz;
+    offB0 = (unsigned)(wave * 8 + rin) * ldw_b + swz;
+  }
+  __amdgpu_buffer_rsrc_t rsA, rsB;
   auto tile_sources = [&](int tile, int& m0, int& n0) {
     const int tm = RR ? tile / tilesN : mp0 + tile / tnn, tn = RR ? tile % tilesN : tn0 + tile % tnn;
     m0 = tm * BM;
     n0 = tn * BN;
     rot = (tn * (g.nblock > 0 ? g.nblock - 1 : 1)) % nk;
-    const int mb = ABL == 2 ? 0 : m0;
-    a_tile = reinterpret_cast<const char*>(g.A) + (size_t)mb * lda_b;
-    // (rebuilt from an opaque copy of the lane id: what is only needed here, once per tile, must not stay in registers - or in
-    // scratch - across the K loop; the same in the epilogue below)
-    int lane_s = lane;
-    asm volatile("" : "+v"(lane_s));
-    const int rin = lane_s >> 3, pc = lane_s & 7;
-    const unsigned swz = (unsigned)((pc ^ ((wave * 4 + (rin >> 1)) & 7)) << 4);
-#pragma unroll
-    for (int i = 0; i < LPA; ++i) {
-      const int row = min((wave + i * NW) * 8 + rin, g.M - 1 - mb);
-      offA[i] = (unsigned)row * lda_b + swz;
-    }
-#pragma unroll
-    for (int i = 0; i < LPB; ++i) {
-      const int gr = min((ABL == 2 ? 0 : n0) + (wave + i * NW) * 8 + rin, g.N - 1);
-      offB[i] = (unsigned)gr * ldw_b + swz;
-    }
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + (size_t)m0 * lda_b, 0,
+                                            (int)((unsigned)min(BM, g.M - m0) * lda_b), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + (size_t)n0 * ldw_b, 0,
+                                            (int)((unsigned)min(BN, g.N - n0) * ldw_b), 0x00020000);
   };
-  auto stage_piece = [&](int stage, int kt, auto IDX) {  // piece IDX (0..3 activations, 4..7 weights) of K-step kt -> stage
+  // One LDS-DMA piece: 64 lanes x 16 bytes -> 1 KiB of LDS at lds_addr (M0) + 16 lane.  Spelled as inline asm: through the builtin
+  // (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc orders every piece behind the LDS READS in flight (an `s_waitcnt lgkmcnt`
+  // in front of each one - the fragment reads of the next MFMA group had just been issued), which no piece needs: a stage is
+  // refilled only after the hand-over barrier that follows its last read.  Nothing else in this kernel uses M0, and the kernel
+  // counts its vector-memory queue by hand (wait_vmcnt) - hipcc's own counted waits (epilogue loads / stores) only err on the
+  // safe side when they do not know of the pieces.
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // ("m0" is a reserved register: that it is ours to set is the point)
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+#pragma clang diagnostic pop
+  };
+  auto stage_piece = [&](int stage, int kt, auto IDX) {  // piece IDX (0..LPA-1 activations, then weights) of K-step kt -> stage
     constexpr int idx = decltype(IDX)::value;
     kt += rot;
     if (kt >= nk) kt -= nk;
-    char* dst = smem + stage * STAGE + wave * 1024;
+    const unsigned dst = lds0 + wave * 1024;
     if constexpr (idx < LPA)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(a_tile + (offA[idx] + (unsigned)kt * X2_GROUP_BYTES)),
-          (__attribute__((address_space(3))) void*)(dst + idx * NW * 1024), 16, 0, 0);
+      dma_piece(rsA, dst + stage * STG_A + idx * NW * 1024, offA0 + (unsigned)(idx * NW * 8) * lda_b, kt * X2_GROUP_BYTES);
     else
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g.W) + (offB[idx - LPA] + (unsigned)kt * X2_GROUP_BYTES)),
-          (__attribute__((address_space(3))) void*)(dst + BM * ROWB + (idx - LPA) * NW * 1024), 16, 0, 0);
+      dma_piece(rsB, dst + OFF_W + stage * STG_W + (idx - LPA) * NW * 1024, offB0 + (unsigned)((idx - LPA) * NW * 8) * ldw_b, kt * X2_GROUP_BYTES);
   };
-  auto stage_load = [&](int stage, int kt) {  // all eight pieces
+  auto stage_load = [&](int stage, int kt) {
     static_for<LPW>([&](auto I) { stage_piece(stage, kt, I); });
   };
+  __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.bias), 0, g.N * 4, 0x00020000);
   auto bias_load = [&](int buf, int n0) {  // BN floats -> LDS by one LDS-DMA of wave 0 (older than that tile's first K-step)
-    if (wave == 0) {
-      const float* p = g.bias + min(n0 + lane * 4, g.N - 4);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                       (__attribute__((address_space(3))) void*)(smem + OFF_BIAS + buf * 1024), 16, 0, 0);
-    }
+    if (wave == 0) dma_piece(rsBias, lds0 + OFF_BIAS + buf * 1024, (unsigned)(n0 + lane * 4) * 4u, 0);   // (columns beyond N: nothing fetched)
   };
 
-  // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads the 16 bytes k = 8h .. 8h+7 of k-half kh of plane p of tile
-  // row r: logical chunk 4 p + 2 kh + h
-  int foff[2][2];
+  // fragment addresses: lane (r = lane & 15, q = lane >> 4) reads the 16 bytes k = 8 q .. 8 q + 7 of plane p of tile row r:
+  // logical chunk 4 p + q of a row whose swizzle key is (row >> 1) & 7 = (r >> 1) & 7 (row tiles start at multiples of 16)
+  int foff[2];
   int a_base, b_base;
   {
-    const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) foff[p][kh] = ((4 * p + 2 * kh + h) ^ f) << 4;
+    const int r = lane & 15, q = lane >> 4, f = (r >> 1) & 7;
+    foff[0] = (q ^ f) << 4;
+    foff[1] = ((4 + q) ^ f) << 4;
     a_base = (wm * TM + r) * ROWB;
-    b_base = (BM + wn * TN + r) * ROWB;
+    b_base = OFF_W + (wn * TN + r) * ROWB;
   }
-  auto read_w = [&](const char* st, int kh, f16x8 (&w)[2][FN]) {
+  auto read_w = [&](int stage, int p, f16x8 (&w)[FN]) {  // plane p of the four column tiles
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) w[p][j] = *reinterpret_cast<const f16x8*>(st + b_base + j * 32 * ROWB + foff[p][kh]);
+    for (int j = 0; j < FN; ++j) w[j] = *reinterpret_cast<const f16x8*>(smem + b_base + foff[p] + (stage * STG_W + j * 16 * ROWB));
   };
-  auto read_a = [&](const char* st, int kh, int i, f16x8 (&a)[2]) {
+  auto read_a = [&](int stage, int i, f16x8 (&a)[2]) {   // both planes of row tile i
 #pragma unroll
-    for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const f16x8*>(st + a_base + i * 32 * ROWB + foff[p][kh]);
+    for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const f16x8*>(smem + a_base + foff[p] + (stage * STG_A + i * 16 * ROWB));
   };
 
   int m0, n0;
@@ -172,61 +187,70 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   bias_load(0, n0);
   stage_load(0, 0);
   stage_load(1, 1);
-  f16x8 wf[2][2][FN];   // [k-half][plane][column tile]
-  f16x8 ws[FN];         // 2^-11 g1 of the current k-half
-  f16x8 af[2][2];       // [group parity][plane]
-  wait_vmcnt<LPW>();    // the bias slice and K-step 0 of the first tile have landed
+  f16x8 g1[FN], g2[FN], gs[FN];   // weight planes of the current K-step; gs = 2^-11 g1
+  f16x8 af[NAF][2];               // [row tile % NAF][plane]
+  wait_vmcnt<LPW>();              // the bias slice and K-step 0 of the first tile have landed
   block_barrier();
-  read_w(smem, 0, wf[0]);
-  read_a(smem, 0, 0, af[0]);
+  read_w(0, 0, g1);
+  read_w(0, 1, g2);
+  read_a(0, 0, af[0]);
   int it = 0;                 // tile iteration (bias buffer = it & 1)
   bool prev_counted = false;  // the previous tile issued exactly NST stores behind its prefetches
+  unsigned long long st_data = 0, st_bar = 0, st_k = 0, st_epi = 0, st_mark = 0, st_tiles = 0;   // (ABL == 4)
+  auto stamp = [] { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
 
   for (;;) {
-    f32x16 acc[FM][FN];
+    f32x4 acc[FM][FN];
     {
-      // the accumulators start from s * bias: register t of a lane is column (t & 3) + 8 (t >> 2) + 4 h of its row
-      const float* biasb = reinterpret_cast<const float*>(smem + OFF_BIAS + (it & 1) * 1024) + wn * TN + 4 * (lane >> 5);
+      // the accumulators start from s * bias: register t of lane (c, q) of column tile j is column 16 j + 4 q + t of its row
+      const float* biasb = reinterpret_cast<const float*>(smem + OFF_BIAS + (it & 1) * 1024) + wn * TN + 4 * (lane >> 4);
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(biasb + j * 16) * w_s;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(biasb + j * 32 + gq * 8) * w_s;
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][gq * 4 + e] = b[e];
-        }
+        for (int i = 0; i < FM; ++i) acc[i][j] = b;
       }
     }
     const int cm0 = m0, cn0 = n0;
     const int tnext = t + (RR ? G : nblk);
     const bool has_next = tnext < t_end;
 
-    // one K-step; PAR = kt & 1 = its stage (nk is even, so every tile starts in stage 0)
-    auto kstep = [&](int kt, auto PAR) {
+    // one K-step; PAR = kt & 1 = its stage (nk is even, so every tile starts in stage 0); FIRST = K-step 0 of a tile, whose
+    // successor is already in flight (requested in front of the previous tile's epilogue stores, or by the prologue): the body is
+    // instantiated once more for it, so that the steady-state groups are ONE basic block each (a uniform branch around the LDS-DMA
+    // pieces cut every group in two, and hipcc's schedule - the LDS reads of the next group early - stopped at the cut)
+    auto kstep = [&](int kt, auto PAR, auto FIRST) {
       constexpr int par = decltype(PAR)::value;
-      const char* st = smem + par * STAGE;
+      constexpr bool first = decltype(FIRST)::value;
       const bool last = kt == nk - 1;
       static_for<NG>([&](auto U) {
         constexpr int u = decltype(U)::value;
-        constexpr int kh = u / FM, i = u % FM;
-        if constexpr (u + 1 < NG) {
-          // fragments of the next group (same K-step) are requested before this group's MFMAs
-          constexpr int kh1 = (u + 1) / FM, i1 = (u + 1) % FM;
-          if constexpr (i1 == 0) read_w(st, kh1, wf[kh1]);
-          read_a(st, kh1, i1, af[(u + 1) & 1]);
+        constexpr bool tail = u + 1 == NG;
+        if constexpr (!tail) {
+          // the planes of the row tile PF groups ahead are requested before this group's MFMAs (PF = 2: the first group of a
+          // K-step requests two row tiles - the hand-over in front of the last group has only published row tile 0)
+          if constexpr (PF == 1) read_a(par, u + 1, af[(u + 1) % NAF]);
+          else {
+            if constexpr (u == 0) read_a(par, 1, af[1]);
+            if constexpr (u + 2 < NG) read_a(par, u + 2, af[(u + 2) % NAF]);
+          }
         } else {
           if (!last || has_next) {
             // hand-over to the next K-step in front of the LAST group: every LDS read of this stage has been issued; once they
             // have returned the stage may be refilled (with K-step kt + 2)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned long long s0 = 0, s1 = 0;
+            if constexpr (ABL == 4) s0 = stamp();
             if constexpr (ABL < 5) {
-              // K-step kt + 1 must have landed; younger than it in this wave's queue are only - at the first step of a tile that
-              // follows a fully stored one - the NST epilogue stores
               if (kt == 0 && prev_counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
             }
+            if constexpr (ABL == 4) s1 = stamp();
             block_barrier();
+            if constexpr (ABL == 4) {
+              const unsigned long long s2 = stamp();
+              st_data += s1 - s0;
+              st_bar += s2 - s1;
+            }
             if (ABL != 1 && ABL < 5) {
               if (kt + 2 < nk) {
                 static_for<LPW>([&](auto I) {
@@ -245,55 +269,65 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
               }
             }
           }
-          // the first fragments of the next K-step, UNCONDITIONALLY (after the last step of the last tile they are never used):
-          // a branch around them would put them in a basic block of their own in front of this group's first MFMA
-          const char* nxs = smem + (par ^ 1) * STAGE;
-          read_w(nxs, 0, wf[0]);
-          read_a(nxs, 0, 0, af[0]);
+          // the first activation fragments of the next K-step, UNCONDITIONALLY (after the last step of the last tile they are
+          // never used): a branch around them would put them in a basic block of their own in front of this group's first MFMA
+          read_a(par ^ 1, 0, af[0]);
         }
-        if constexpr (i == 0) {
-          // the third weight operand of this k-half: 2^-11 g1 (exact for g1 >= 2^-3; below, its error is 2^-25 absolute on a term
+        if constexpr (u == 0) {
+          // the third weight operand of this K-step: 2^-11 g1 (exact for g1 >= 2^-3; below, its error is 2^-25 absolute on a term
           // that is 2^-11 of the product)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) ws[j] = wf[kh][0][j] * static_cast<_Float16>(1.f / X2_RESID_SCALE);
+          for (int j = 0; j < FN; ++j) gs[j] = g1[j] * static_cast<_Float16>(1.f / X2_RESID_SCALE);
         }
         // products in issue order: g1 h1, g2 h1, (2^-11 g1) h2 - consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh][0][j], af[u & 1][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1[j], af[u % NAF][0], acc[u][j], 0, 0, 0);
+        if constexpr (tail) read_w(par ^ 1, 0, g1);   // plane by plane: the next K-step's weights take the registers just released
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh][1][j], af[u & 1][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g2[j], af[u % NAF][0], acc[u][j], 0, 0, 0);
+        if constexpr (tail) read_w(par ^ 1, 1, g2);
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws[j], af[u & 1][1], acc[i][j], 0, 0, 0);
-        if constexpr (SPREAD > 0 && ABL != 1 && ABL < 5 && u + 1 < NG) {
-          constexpr bool any = x2_piece_slot(SPREAD, 0, LPA) == u || x2_piece_slot(SPREAD, 1, LPA) == u || x2_piece_slot(SPREAD, 2, LPA) == u ||
-                               x2_piece_slot(SPREAD, 3, LPA) == u || x2_piece_slot(SPREAD, 4, LPA) == u || x2_piece_slot(SPREAD, 5, LPA) == u ||
-                               (LPW > 6 && (x2_piece_slot(SPREAD, 6, LPA) == u || x2_piece_slot(SPREAD, 7, LPA) == u));
-          if constexpr (any) {
-            // K-step kt + 1 (or K-step 0 of the next tile) into the stage the previous hand-over released
-            if (kt > 0 && (kt + 1 < nk || has_next)) {
-              const int lk = kt + 1 < nk ? kt + 1 : 0;
-              static_for<LPW>([&](auto I) {
-                if constexpr (x2_piece_slot(SPREAD, decltype(I)::value, LPA) == u) stage_piece(par ^ 1, lk, I);
-              });
-            }
-          }
+        for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gs[j], af[u % NAF][1], acc[u][j], 0, 0, 0);
+        if constexpr (SPREAD > 0 && ABL != 1 && ABL < 5 && !tail && !first) {
+          // K-step kt + 1 (or K-step 0 of the next tile) into the stage the previous hand-over released - UNCONDITIONALLY: behind
+          // the last K-step of a workgroup's last tile the pieces fetch K-step 0 of that tile once more (valid addresses, a stage
+          // nobody reads; drained before the kernel ends)
+          const int lk = kt + 1 < nk ? kt + 1 : 0;
+          static_for<LPW>([&](auto I) {
+            if constexpr (x2_piece_slot(SPREAD, decltype(I)::value, LPA) == u) stage_piece(par ^ 1, lk, I);
+          });
         }
-        // issue order inside a group: ONE MFMA, then the LDS reads of the next group, then the other MFMAs (hipcc would
-        // otherwise sink the reads next to their first use, and its wait for this group's operands would cover them)
-        constexpr int kReads = (u + 1 < NG) ? (((u + 1) % FM == 0) ? 2 * FN : 0) + 2 : 2 * FN + 2;
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * FN - 1, 0);
+        // issue order inside a group: ONE MFMA, then the LDS reads of the next group, then the other MFMAs (hipcc would otherwise
+        // sink the reads next to their first use, and its wait for this group's operands would cover them); in the last group the
+        // weight planes of the next K-step follow the four MFMAs that last used their registers
+        if constexpr (!tail) {
+          constexpr int kReads = PF == 1 ? 2 : (u == 0 ? 4 : u + 2 < NG ? 2 : 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if constexpr (kReads > 0) __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * FN - 1, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, FN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, FN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+        }
       });
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-      kstep(kt, std::integral_constant<int, 0>{});
-      kstep(kt + 1, std::integral_constant<int, 1>{});
+    if constexpr (ABL == 4) st_mark = stamp();
+    kstep(0, std::integral_constant<int, 0>{}, std::true_type{});
+    kstep(1, std::integral_constant<int, 1>{}, std::false_type{});
+    for (int kt = 2; kt < nk; kt += 2) {
+      kstep(kt, std::integral_constant<int, 0>{}, std::false_type{});
+      kstep(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
-    // wf[0] / af[0] now hold the first fragments of the next tile
+    // g1 / g2 / af[0] now hold the first fragments of the next tile
+    if constexpr (ABL == 4) {
+      const unsigned long long now = stamp();
+      st_k += now - st_mark;
+      st_mark = now;
+    }
 
     const bool interior = cm0 + BM <= g.M && cn0 + BN <= g.N;
     if constexpr (ABL == 3 || ABL >= 6) {
@@ -303,118 +337,124 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+          for (int e = 0; e < 4; ++e) keep += acc[i][j][e];
       if (keep == 123.456f) reinterpret_cast<float*>(g.C)[0] = keep;
       prev_counted = false;
     } else {
-      char* stg = smem + OFF_STG + wave * 2048;
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));
-      const int r = lane_e & 31, h = lane_e >> 5, r16 = r & 15, myhp = r >> 4;   // (epilogue-local copies)
-      // patch: 16 rows x 128 bytes; 16-byte chunk c of row q at chunk c ^ key(q), key(q) = (q & 7) ^ (q >> 3): conflict-free both ways
-      const int key = (r16 & 7) ^ (r16 >> 3);
-      const int rrow = lane_e >> 3, rch = lane_e & 7;
-      // The patch is written by HALF the lanes and read by all of them: to the compiler a lane that did not write sees "the same"
-      // LDS contents as in the previous half pass (it sank the read into the exec-masked write block: the other lanes stored stale
-      // registers - rows 0, 1, 4, 5 of every second half pass).  LDS operations of a wave execute in order; what is needed is only
-      // that the compiler neither reuses nor moves them across this point.
-      auto patch_fence = [] { asm volatile("" ::: "memory"); };
-      const int rd_off[2] = {rrow * 128 + ((rch ^ rrow) << 4), (8 + rrow) * 128 + ((rch ^ rrow ^ 1) << 4)};
-      if constexpr (!kOutX2) {
-        // EPI_RESID3_F32: every lane adds the 16 bytes of C it is about to overwrite (the residual stream, updated in place);
-        // they are requested RW tiles ahead, whole lines per instruction and non-temporal, like the stores
-        constexpr int RWIN = RW, NT = FM * FN;
-        f32x4 xres[kResid ? RWIN : 1][4];
-        auto resid_load = [&](int tl, f32x4 (&dst)[4]) {
-          const int i = tl / FN, j = tl % FN;
+      // The tile's position is decided ONCE: an interior tile (the hot case) runs a branch-free body - with a uniform branch
+      // around every store hipcc had put each LDS read, its wait and its store in a basic block of their own, the round trip
+      // through the patch exposed 32 times per tile; in straight-line code the next patch's arithmetic fills it
+      auto epilogue = [&](auto INTERIOR) {
+        constexpr bool inter = decltype(INTERIOR)::value;
+        char* stg = smem + OFF_STG + wave * 2048;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int c = lane_e & 15, q = lane_e >> 4;   // (epilogue-local copies)
+        // patch: 16 rows x 128 bytes; 16-byte chunk L of row c at chunk L ^ key(c), key(c) = (c & 7) ^ (c >> 3): conflict-free both ways
+        const int key = (c & 7) ^ (c >> 3);
+        const int rrow = lane_e >> 3, rch = lane_e & 7;
+        // LDS operations of a wave execute in order; the compiler must neither reuse nor move them across the write -> read and the
+        // read -> next write points of a patch
+        auto patch_fence = [] { asm volatile("" ::: "memory"); };
+        // (the interior body is one basic block of 16 patches: without a scheduling fence per patch hipcc computes several patches
+        // ahead and spills ~90 registers)
+        auto patch_end = [&] { patch_fence(); __builtin_amdgcn_sched_barrier(0); };
+        const int rd_off[2] = {rrow * 128 + ((rch ^ rrow) << 4), (8 + rrow) * 128 + ((rch ^ rrow ^ 1) << 4)};
+        if constexpr (!kOutX2) {
+          // EPI_RESID3_F32: every lane adds the 16 bytes of C it is about to overwrite (the residual stream, updated in place);
+          // they are requested RW patches ahead, whole lines per instruction and non-temporal, like the stores
+          constexpr int RWIN = RW;
+          f32x4 xres[kResid ? RWIN : 1][2];
+          auto resid_load = [&](int pt, f32x4 (&dst)[2]) {
+            const int i = pt / (FN / 2), jp = pt % (FN / 2);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int mo = cm0 + wm * TM + i * 32 + s * 8 + rrow, no = cn0 + wn * TN + j * 32 + rch * 4;
-            dst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (interior || (mo < g.M && no < g.N))
-              dst[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (size_t)mo * g.ldc + no));
+            for (int s = 0; s < 2; ++s) {
+              const int mo = cm0 + wm * TM + i * 16 + s * 8 + rrow, no = cn0 + wn * TN + jp * 32 + rch * 4;
+              dst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (inter || (mo < g.M && no < g.N))
+                dst[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (size_t)mo * g.ldc + no));
+            }
+          };
+          if constexpr (kResid) {
+#pragma unroll
+            for (int pt = 0; pt < RWIN && pt < NP; ++pt) resid_load(pt, xres[pt]);
           }
-        };
-        if constexpr (kResid) {
+          char* wr = stg + c * 128;
 #pragma unroll
-          for (int tl = 0; tl < RWIN && tl < NT; ++tl) resid_load(tl, xres[tl]);
-        }
-        char* wr = stg + r16 * 128;
+          for (int i = 0; i < FM; ++i) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+            for (int jp = 0; jp < FN / 2; ++jp) {
+              const int pt = i * (FN / 2) + jp;
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-#pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-              if (myhp == hp) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                  const f32x4 v = f32x4{acc[i][j][gq * 4], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]} * w_inv;
-                  *reinterpret_cast<f32x4*>(wr + (((2 * gq + h) ^ key) << 4)) = v;
-                }
-              }
+              for (int jj = 0; jj < 2; ++jj)
+                *reinterpret_cast<f32x4*>(wr + (((4 * jj + q) ^ key) << 4)) = acc[i][2 * jp + jj] * w_inv;
               patch_fence();
 #pragma unroll
               for (int s = 0; s < 2; ++s) {
                 f32x4 val = *reinterpret_cast<const f32x4*>(stg + rd_off[s]);
-                if constexpr (kResid) val = xres[(i * FN + j) % RWIN][hp * 2 + s] + val;
-                const int mo = cm0 + wm * TM + i * 32 + hp * 16 + s * 8 + rrow, no = cn0 + wn * TN + j * 32 + rch * 4;
-                if (interior || (mo < g.M && no < g.N)) {
+                if constexpr (kResid) val = xres[pt % RWIN][s] + val;
+                const int mo = cm0 + wm * TM + i * 16 + s * 8 + rrow, no = cn0 + wn * TN + jp * 32 + rch * 4;
+                if (inter || (mo < g.M && no < g.N)) {
                   f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)mo * g.ldc + no);
                   __builtin_nontemporal_store(val, dst);
                 }
               }
-              patch_fence();
-            }
-            if constexpr (kResid) {
-              if (i * FN + j + RWIN < NT) resid_load(i * FN + j + RWIN, xres[(i * FN + j) % RWIN]);
+              if constexpr (kResid) {
+                if (pt + RWIN < NP) resid_load(pt + RWIN, xres[pt % RWIN]);
+              }
+              patch_end();
             }
           }
-        }
-      } else {
-        // x2 outputs (the next GEMM's activation operand): exact QuickGELU, then the two fp16 planes; a 32 x 32 tile is ONE
-        // 128-byte line [h1 x32 | h2 x32] of 32 rows: quad gq of a lane (columns 8 gq + 4 h ..) is the 8 bytes at 16 gq + 8 h of
-        // either plane
-        const size_t ldc_b = (size_t)g.ldc * 2;
-        char* cbase = reinterpret_cast<char*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * ldc_b + rch * 16;
-        char* wr = stg + r16 * 128 + h * 8;
-        float amax = 0.f;
+        } else {
+          // x2 outputs (the next GEMM's activation operand): exact QuickGELU, then the two fp16 planes; two column tiles are ONE
+          // 128-byte line [h1 x32 | h2 x32] of 16 rows: the four values of lane (c, q) in column tile jj are the 8 bytes at
+          // 32 jj + 8 q of either plane = half (q & 1) of chunk 2 jj + (q >> 1) (+ 4 for the second plane).  The planes of patch
+          // pt + 1 are computed between the writes and the reads of patch pt.
+          const size_t ldc_b = (size_t)g.ldc * 2;
+          char* cbase = reinterpret_cast<char*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * ldc_b + rch * 16;
+          char* wr = stg + c * 128 + (q & 1) * 8;
+          const int qh = q >> 1;
+          float amax = 0.f;
+          f16x4 h1[2][2], h2[2][2];   // [patch parity][column tile]
+          auto planes = [&](auto PT) {
+            constexpr int pt = decltype(PT)::value, i = pt / (FN / 2), jp = pt % (FN / 2);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            f16x4 h1[4], h2[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-              f32x4 v = f32x4{acc[i][j][gq * 4], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]} * w_inv;
+            for (int jj = 0; jj < 2; ++jj) {
+              f32x4 v = acc[i][2 * jp + jj] * w_inv;
               v = quick_gelu_f32x4(v);  // (packed pairs; the bits of quick_gelu_exact)
               amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-              split2(v, h1[gq], h2[gq]);
+              split2(v, h1[pt & 1][jj], h2[pt & 1][jj]);
             }
-            const int group = (cn0 + wn * TN + j * 32) / X2_GROUP;                       // wave-uniform
-            char* tile_base = cbase + (size_t)(i * 32) * ldc_b + (size_t)group * X2_GROUP_BYTES;
+            asm volatile("" : "+v"(amax));   // (the running maximum is taken HERE: hipcc otherwise keeps the values for one reduction at the end)
+          };
+          planes(std::integral_constant<int, 0>{});
+          static_for<NP>([&](auto PT) {
+            constexpr int pt = decltype(PT)::value, i = pt / (FN / 2), jp = pt % (FN / 2);
+            const int group = (cn0 + wn * TN + jp * 32) / X2_GROUP;                       // wave-uniform
+            char* tile_base = cbase + (size_t)(i * 16) * ldc_b + (size_t)group * X2_GROUP_BYTES;
 #pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-              if (myhp == hp) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                  *reinterpret_cast<f16x4*>(wr + ((gq ^ key) << 4)) = h1[gq];
-                  *reinterpret_cast<f16x4*>(wr + (((4 + gq) ^ key) << 4)) = h2[gq];
-                }
-              }
-              patch_fence();
-#pragma unroll
-              for (int s = 0; s < 2; ++s) {
-                const f16x8 val = *reinterpret_cast<const f16x8*>(stg + rd_off[s]);
-                const int mo = cm0 + wm * TM + i * 32 + hp * 16 + s * 8 + rrow;
-                if (interior || (mo < g.M && group * X2_GROUP < g.N))
-                  __builtin_nontemporal_store(val, reinterpret_cast<f16x8*>(tile_base + (size_t)(hp * 16 + s * 8) * ldc_b));
-              }
-              patch_fence();
+            for (int jj = 0; jj < 2; ++jj) {
+              *reinterpret_cast<f16x4*>(wr + (((2 * jj + qh) ^ key) << 4)) = h1[pt & 1][jj];
+              *reinterpret_cast<f16x4*>(wr + (((4 + 2 * jj + qh) ^ key) << 4)) = h2[pt & 1][jj];
             }
-          }
+            patch_fence();
+            if constexpr (pt + 1 < NP) planes(std::integral_constant<int, pt + 1>{});
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const f16x8 val = *reinterpret_cast<const f16x8*>(stg + rd_off[s]);
+              const int mo = cm0 + wm * TM + i * 16 + s * 8 + rrow;
+              if (inter || (mo < g.M && group * X2_GROUP < g.N))
+                __builtin_nontemporal_store(val, reinterpret_cast<f16x8*>(tile_base + (size_t)(s * 8) * ldc_b));
+            }
+            patch_end();
+          });
+          if (g.sat_flag && !(amax <= 65504.f)) atomicOr(g.sat_flag, 1);
         }
-        if (g.sat_flag && !(amax <= 65504.f)) atomicOr(g.sat_flag, 1);   // (also when amax is NaN)
+      };
+      if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
+      if constexpr (ABL == 4) {
+        st_epi += stamp() - st_mark;
+        ++st_tiles;
       }
       prev_counted = interior;
     }
@@ -422,6 +462,13 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
     ++it;
     t = tnext;
   }
+  if constexpr (ABL == 4) {
+    if (lane == 0 && g.aux) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.aux)) + ((size_t)blockIdx.x * NW + wave) * 8;
+      d[0] = st_data; d[1] = st_bar; d[2] = st_k; d[3] = st_epi; d[4] = st_tiles; d[5] = (unsigned long long)nk;
+    }
+  }
+  wait_vmcnt<0>();   // (the unread pieces behind the last K-step: no LDS-DMA may be in flight when the workgroup's LDS is released)
 }
 
 }  // namespace

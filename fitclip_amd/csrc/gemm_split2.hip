@@ -13,9 +13,10 @@ constexpr int split2_lds(int bm) { return 2 * (bm + 256) * 128 + 8 * 2048 + 2048
 
 template <int EPI, int RW, int BMT>
 int launch_x2_tiles(const GemmArgs& a, hipStream_t stream) {
-  // SPREAD = 3: the LDS-DMA pieces of a K-step are issued two at a time behind the first MFMA groups of the step before it is
-  // needed, none in the hand-over (tools/split2_lab: 2 - 4 % over a burst at the hand-over on all four block shapes)
-  auto kern = gemm_split2_kernel<EPI, 0, 3, RW, 0, BMT>;
+  // SPREAD = 5: the LDS-DMA pieces of a K-step are issued 3, 3, 2 behind the first three MFMA groups of the step before it is
+  // needed, none in the hand-over (tools/x2k_lab: up to 1.7 % over two behind each of the first four groups, which round 5 had
+  // measured 2 - 4 % over a burst at the hand-over)
+  auto kern = gemm_split2_kernel<EPI, 0, 5, RW, 0, BMT>;
   constexpr int lds = split2_lds(BMT);
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split2: cannot raise dynamic LDS to %d bytes", lds);
@@ -42,7 +43,7 @@ bool x2_use_half_tiles(int M, int N, int cus, int force) {
   return tiles256 <= cus;
 }
 
-template <int EPI, int RW = 2>
+template <int EPI, int RW = 4>
 int launch_x2_variant(const GemmArgs& a, hipStream_t stream, int force) {
   return x2_use_half_tiles(a.M, a.N, device_cus(), force) ? launch_x2_tiles<EPI, RW, 128>(a, stream)
                                                           : launch_x2_tiles<EPI, RW, 256>(a, stream);
@@ -160,7 +161,7 @@ int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int 
       return launch_x2_variant<EPI_BIAS_F32>(b, stream, force_cut);
     case EPI_RESID3_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);
-      return launch_x2_variant<EPI_RESID3_F32, 2>(b, stream, force_cut);
+      return launch_x2_variant<EPI_RESID3_F32>(b, stream, force_cut);
     case EPI_GELU_X2:
       if (a.ldc % 64 || a.ldc < x2_row_elems(a.N) || ((uintptr_t)a.C & 127))
         return fail(FC_EINVAL, "gemm_split2: the x2 output needs 128-byte aligned rows of >= 2 N fp16 (ldc=%d)", a.ldc);

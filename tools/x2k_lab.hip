@@ -1,10 +1,11 @@
-// Lab for the two-plane fp16 split-fp32 GEMM (fitclip_amd/csrc/gemm_split2.h): accuracy against a float64 dot product of the
-// fp32 operands on sampled outputs (next to the three-plane bf16 kernel, gemm_split3.h, on the same operands), timing on the
-// four block shapes, ablations, and what the fp16 matrix cores do with subnormal inputs.  Not part of the library.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fitclip_amd/csrc -I include tools/split2_lab.hip -o tools/bin/split2_lab
-//   tools/bin/split2_lab [M] [reps] [rounds] [activation scale] [weight scale] [only variants whose name contains this]
+// Lab for the MFMA shape of the two-plane fp16 split-fp32 GEMM: the 32x32x16 kernel (tools/gemm_split2_m32.h, round 5's shipped
+// kernel) next to the 16x16x32 kernel (fitclip_amd/csrc/gemm_split2.h) on the same x2 operands - accuracy against a float64 dot
+// product of the fp32 operands on sampled outputs, interleaved timing rounds on the four block shapes, ablations of both.
+// Not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fitclip_amd/csrc -I include -I tools tools/x2k_lab.hip -o tools/bin/x2k_lab
+//   tools/bin/x2k_lab [M] [reps] [rounds] [activation scale] [weight scale] [only variants whose name contains this]
 #include "gemm_split2.hip"
-#include "gemm_split3.hip"
+#include "gemm_split2_m32.h"
 
 #include <algorithm>
 #include <cmath>
@@ -59,11 +60,7 @@ __global__ void check(const float* A, const float* W, const float* bias, const v
   for (int k = 0; k < K; ++k) acc += (double)A[(size_t)m * K + k] * (double)W[(size_t)n * K + k];
   acc += bias[n];
   double got;
-  if (kind == 3) {
-    acc = acc / (1.0 + exp(-1.702 * acc));
-    const bf16* line = reinterpret_cast<const bf16*>(C) + (size_t)m * ldc + (size_t)(n / 16) * 64 + (n % 16);
-    got = (double)(float)line[0] + (double)(float)line[16] + (double)(float)line[32];
-  } else if (kind == 2) {
+  if (kind == 2) {
     acc = acc / (1.0 + exp(-1.702 * acc));
     const _Float16* line = reinterpret_cast<const _Float16*>(C) + (size_t)m * ldc + (size_t)(n / 32) * 64 + (n % 32);
     got = (double)(float)line[0] + (double)(float)line[32] / 2048.0;
@@ -74,24 +71,9 @@ __global__ void check(const float* A, const float* W, const float* bias, const v
   out[2 * s + 1] = got;
 }
 
-// what v_mfma_f32_32x32x16_f16 does with subnormal fp16 inputs: D = A(all rows = a) x B(all = b), k = 16 products
-__global__ void denorm_probe(float a, float b, float* out) {
-  f16x8 va, vb;
-  for (int e = 0; e < 8; ++e) { va[e] = static_cast<_Float16>(a); vb[e] = static_cast<_Float16>(b); }
-  f32x16 acc;
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, vb, acc, 0, 0, 0);
-  if (threadIdx.x == 0) {
-    out[0] = acc[0];
-    out[1] = (float)static_cast<_Float16>(a);
-    const f16x8 vs = va * static_cast<_Float16>(1.f / 2048.f);
-    out[2] = (float)vs[0];
-  }
-}
-
 template <int EPI, int ABL, int SPREAD = 0, int RW = 2, int RR = 0>
-void launch_x2(const GemmArgs& a, hipStream_t st) {
-  auto kern = gemm_split2_kernel<EPI, ABL, SPREAD, RW, RR>;
+void launch_m32(const GemmArgs& a, hipStream_t st) {   // the 32x32x16 kernel
+  auto kern = gemm_split2_m32_kernel<EPI, ABL, SPREAD, RW, RR>;
   static bool configured = false;
   if (!configured) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSplit2Lds));
@@ -100,17 +82,16 @@ void launch_x2(const GemmArgs& a, hipStream_t st) {
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), kSplit2Lds, st, a);
 }
-template <int EPI>
-void launch_x3(const GemmArgs& a, hipStream_t st) {  // the shipped three-plane kernel (SPREAD = 1)
-  constexpr int lds = 3 * 512 * 96 + 2048;
-  auto kern = gemm_split3_kernel<EPI, 0, 1, (EPI == EPI_RESID3_F32 ? 2 : 4)>;
+template <int EPI, int ABL, int SPREAD = 0, int RW = 4, int PF = 1>
+void launch_k32(const GemmArgs& a, hipStream_t st) {   // the 16x16x32 kernel
+  auto kern = gemm_split2_kernel<EPI, ABL, SPREAD, RW, 0, 256, PF>;
   static bool configured = false;
   if (!configured) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSplit2Lds));
     configured = true;
   }
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), kSplit2Lds, st, a);
 }
 
 int main(int argc, char** argv) {
@@ -124,87 +105,63 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
-  {
-    float* d;
-    HIP_OK(hipMalloc(&d, 64));
-    const float cases[][2] = {{1.f, 1.f}, {3.0e-5f, 1024.f}, {6.0e-8f, 16384.f}, {3.0e-5f, 3.0e-5f}, {1.0e-3f, 1.f}};
-    for (auto& c : cases) {
-      denorm_probe<<<1, 64, 0, st>>>(c[0], c[1], d);
-      float h[3];
-      HIP_OK(hipMemcpyAsync(h, d, 12, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipStreamSynchronize(st));
-      const float a16 = h[1], b16 = (float)(_Float16)c[1];
-      printf("denorm probe: a=%g (fp16 %g) b=%g: mfma sum of 16 products = %.9g, expected %.9g;  a * 2^-11 as v_pk_mul_f16 = %g (exact %g)\n",
-             c[0], a16, c[1], h[0], 16.0 * (double)a16 * (double)b16, h[2], a16 / 2048.0);
-    }
-    HIP_OK(hipFree(d));
-  }
   struct Shape { const char* name; int N, K, epi; };   // epi: 0 = fp32 rows out, 1 = QuickGELU + plane rows out, 2 = residual update
   const Shape shapes[] = {{"qkv", 2304, 768, 0}, {"out_proj", 768, 768, 2}, {"c_fc", 3072, 768, 1}, {"c_proj", 768, 3072, 2}};
   for (const Shape& sh : shapes) {
     float *A, *W, *bias, *scale2;
-    void *A2, *W2, *A3, *W3, *C;
+    void *A2, *W2, *C;
     double* chk;
     int* flag;
-    const long lda2 = x2_row_elems(sh.K), lda3 = x3_row_elems(sh.K);
-    const long ldc2 = sh.epi == 1 ? x2_row_elems(sh.N) : sh.N, ldc3 = sh.epi == 1 ? x3_row_elems(sh.N) : sh.N;
-    const size_t cbytes = (size_t)M * ldc3 * (sh.epi == 1 ? 2 : 4);   // (the x3 rows are the larger ones)
+    const long lda2 = x2_row_elems(sh.K);
+    const long ldc2 = sh.epi == 1 ? x2_row_elems(sh.N) : sh.N;
+    const size_t cbytes = (size_t)M * ldc2 * (sh.epi == 1 ? 2 : 4);
     HIP_OK(hipMalloc(&A, (size_t)M * sh.K * 4));
     HIP_OK(hipMalloc(&W, (size_t)sh.N * sh.K * 4));
     HIP_OK(hipMalloc(&A2, (size_t)M * lda2 * 2));
     HIP_OK(hipMalloc(&W2, (size_t)sh.N * lda2 * 2));
-    HIP_OK(hipMalloc(&A3, (size_t)M * lda3 * 2));
-    HIP_OK(hipMalloc(&W3, (size_t)sh.N * lda3 * 2));
     HIP_OK(hipMalloc(&C, cbytes));
     HIP_OK(hipMalloc(&bias, sh.N * 4));
     HIP_OK(hipMalloc(&scale2, 8));
     HIP_OK(hipMalloc(&flag, 4));
     HIP_OK(hipMalloc(&chk, 8192 * 2 * 8));
+    unsigned long long* dbg;
+    HIP_OK(hipMalloc(&dbg, 256 * 8 * 8 * 8));
+    HIP_OK(hipMemsetAsync(dbg, 0, 256 * 8 * 8 * 8, st));
     HIP_OK(hipMemsetAsync(flag, 0, 4, st));
     fill_f32<<<2048, 256, 0, st>>>(A, (size_t)M * sh.K, 1u, a_scale);
     fill_f32<<<2048, 256, 0, st>>>(W, (size_t)sh.N * sh.K, 2u, w_mul * 2.0f / sqrtf((float)sh.K));
     fill_f32<<<64, 256, 0, st>>>(bias, sh.N, 3u, 0.5f);
     if (launch_split2_rows(A, sh.K, A2, lda2, M, sh.K, flag, st) || launch_split2_weight(W, sh.K, W2, lda2, sh.N, sh.K, scale2, st)) return 3;
-    if (launch_split3_rows(A, sh.K, A3, lda3, M, sh.K, st) || launch_split3_rows(W, sh.K, W3, lda3, sh.N, sh.K, st)) return 3;
-    float hs[2];
-    int hflag;
-    HIP_OK(hipMemcpyAsync(hs, scale2, 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    printf("%s: weight scale 2^%d (1/s = %g), activation saturation flag %d\n", sh.name, (int)log2f(hs[0]), hs[1], hflag);
     GemmArgs a{};
     a.bias = bias; a.C = C; a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K;
-    struct V { const char* name; void (*fn)(const GemmArgs&, hipStream_t); int x3; int nsplit; int nblock = 0; };
+    a.aux = reinterpret_cast<const float*>(dbg);
+    a.A = A2; a.W = W2; a.lda = (int)lda2; a.ldw = (int)lda2; a.ldc = (int)ldc2; a.wscale = scale2; a.sat_flag = flag;
+    struct V { const char* name; void (*fn)(const GemmArgs&, hipStream_t); int nsplit; };
     std::vector<V> vs;
+    const int ns = sh.epi == 1 ? 4 : 0;
     if (sh.epi == 1) {
-      vs = {{"x3 shipped (nsplit4)", launch_x3<EPI_GELU_X3>, 1, 4},
-            {"x2 gelu", launch_x2<EPI_GELU_X2, 0, 0>, 0, 0}, {"x2 gelu nsplit4", launch_x2<EPI_GELU_X2, 0, 0>, 0, 4},
-            {"x2 gelu spread1 nsplit4", launch_x2<EPI_GELU_X2, 0, 1>, 0, 4}, {"x2 gelu spread2 nsplit4", launch_x2<EPI_GELU_X2, 0, 2>, 0, 4},
-            {"x2 gelu spread3 nsplit4", launch_x2<EPI_GELU_X2, 0, 3>, 0, 4}, {"x2 gelu spread4 nsplit4", launch_x2<EPI_GELU_X2, 0, 4>, 0, 4},
-            {"x2 gelu spread2", launch_x2<EPI_GELU_X2, 0, 2>, 0, 0}, {"x2 gelu spread2 nsplit2", launch_x2<EPI_GELU_X2, 0, 2>, 0, 2},
-            {"x2 gelu spread2 rr", launch_x2<EPI_GELU_X2, 0, 2, 2, 1>, 0, 0},
-            {"x2 gelu spread2 nsplit4 rot0", launch_x2<EPI_GELU_X2, 0, 2>, 0, 4, 1}, {"x2 gelu spread2 nsplit4 rot2", launch_x2<EPI_GELU_X2, 0, 2>, 0, 4, 3},
-            {"x2 gelu ABL2 same tile", launch_x2<EPI_GELU_X2, 2, 2>, 0, 4}, {"x2 gelu ABL3 no-store", launch_x2<EPI_GELU_X2, 3, 2>, 0, 4},
-            {"x2 gelu ABL1 no-loads", launch_x2<EPI_GELU_X2, 1, 2>, 0, 4}, {"x2 gelu ABL6 mfma only", launch_x2<EPI_GELU_X2, 6, 2>, 0, 4}};
+      vs = {{"m32 shipped", launch_m32<EPI_GELU_X2, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_GELU_X2, 0, 3>, ns},
+            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
+            {"m32 ABL1 no-loads", launch_m32<EPI_GELU_X2, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_GELU_X2, 1, 3>, ns},
+            {"m32 ABL3 no-epilogue", launch_m32<EPI_GELU_X2, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_GELU_X2, 3, 3>, ns},
+            {"m32 ABL6 mfma only", launch_m32<EPI_GELU_X2, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_GELU_X2, 6, 3>, ns},
+            {"k32 ABL4 stamps", launch_k32<EPI_GELU_X2, 4, 5>, ns}};
     } else if (sh.epi == 2) {
-      vs = {{"x3 shipped", launch_x3<EPI_RESID3_F32>, 1, 0},
-            {"x2 resid", launch_x2<EPI_RESID3_F32, 0, 0>, 0, 0}, {"x2 resid spread1", launch_x2<EPI_RESID3_F32, 0, 1>, 0, 0},
-            {"x2 resid spread2", launch_x2<EPI_RESID3_F32, 0, 2>, 0, 0}, {"x2 resid spread3", launch_x2<EPI_RESID3_F32, 0, 3>, 0, 0},
-            {"x2 resid spread4", launch_x2<EPI_RESID3_F32, 0, 4>, 0, 0},
-            {"x2 resid spread2 rw4", launch_x2<EPI_RESID3_F32, 0, 2, 4>, 0, 0}, {"x2 resid spread2 rr", launch_x2<EPI_RESID3_F32, 0, 2, 2, 1>, 0, 0},
-            {"x2 resid spread2 rot0", launch_x2<EPI_RESID3_F32, 0, 2>, 0, 0, 1}, {"x2 resid spread2 rot2", launch_x2<EPI_RESID3_F32, 0, 2>, 0, 0, 3},
-            {"x2 bias-only spread2", launch_x2<EPI_BIAS_F32, 0, 2>, 0, 0},
-            {"x2 resid ABL2 same tile", launch_x2<EPI_RESID3_F32, 2, 2>, 0, 0}, {"x2 resid ABL3 no-store", launch_x2<EPI_RESID3_F32, 3, 2>, 0, 0},
-            {"x2 resid ABL1 no-loads", launch_x2<EPI_RESID3_F32, 1, 2>, 0, 0}, {"x2 resid ABL6 mfma only", launch_x2<EPI_RESID3_F32, 6, 2>, 0, 0}};
+      vs = {{"m32 shipped", launch_m32<EPI_RESID3_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_RESID3_F32, 0, 3>, ns},
+            {"k32 spread5", launch_k32<EPI_RESID3_F32, 0, 5>, ns}, {"k32 spread5 pf2", launch_k32<EPI_RESID3_F32, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_RESID3_F32, 4, 5, 4, 2>, ns},
+            {"m32 ABL1 no-loads", launch_m32<EPI_RESID3_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_RESID3_F32, 1, 3>, ns},
+            {"m32 ABL3 no-epilogue", launch_m32<EPI_RESID3_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_RESID3_F32, 3, 3>, ns},
+            {"m32 ABL6 mfma only", launch_m32<EPI_RESID3_F32, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_RESID3_F32, 6, 3>, ns},
+            {"k32 ABL4 stamps", launch_k32<EPI_RESID3_F32, 4, 5>, ns}};
     } else {
-      vs = {{"x3 shipped", launch_x3<EPI_BIAS_F32>, 1, 0},
-            {"x2 f32", launch_x2<EPI_BIAS_F32, 0, 0>, 0, 0}, {"x2 f32 spread1", launch_x2<EPI_BIAS_F32, 0, 1>, 0, 0},
-            {"x2 f32 spread2", launch_x2<EPI_BIAS_F32, 0, 2>, 0, 0}, {"x2 f32 spread3", launch_x2<EPI_BIAS_F32, 0, 3>, 0, 0},
-            {"x2 f32 spread4", launch_x2<EPI_BIAS_F32, 0, 4>, 0, 0}, {"x2 f32 spread2 rr", launch_x2<EPI_BIAS_F32, 0, 2, 2, 1>, 0, 0},
-            {"x2 f32 spread2 rot0", launch_x2<EPI_BIAS_F32, 0, 2>, 0, 0, 1}, {"x2 f32 spread2 rot2", launch_x2<EPI_BIAS_F32, 0, 2>, 0, 0, 3},
-            {"x2 f32 ABL2 same tile", launch_x2<EPI_BIAS_F32, 2, 2>, 0, 0}, {"x2 f32 ABL3 no-store", launch_x2<EPI_BIAS_F32, 3, 2>, 0, 0},
-            {"x2 f32 ABL1 no-loads", launch_x2<EPI_BIAS_F32, 1, 2>, 0, 0}, {"x2 f32 ABL6 mfma only", launch_x2<EPI_BIAS_F32, 6, 2>, 0, 0}};
+      vs = {{"m32 shipped", launch_m32<EPI_BIAS_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_BIAS_F32, 0, 3>, ns},
+            {"k32 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, ns}, {"k32 spread5 pf2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 2>, ns},
+            {"k32 ABL4 stamps pf2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 2>, ns},
+            {"m32 ABL1 no-loads", launch_m32<EPI_BIAS_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_BIAS_F32, 1, 3>, ns},
+            {"m32 ABL3 no-epilogue", launch_m32<EPI_BIAS_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_BIAS_F32, 3, 3>, ns},
+            {"m32 ABL6 mfma only", launch_m32<EPI_BIAS_F32, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_BIAS_F32, 6, 3>, ns},
+            {"k32 ABL4 stamps", launch_k32<EPI_BIAS_F32, 4, 5>, ns}};
     }
     if (argc > 6) {  // (PMC passes: few dispatches - only the variants asked for)
       std::vector<V> keep;
@@ -215,9 +172,6 @@ int main(int argc, char** argv) {
     auto args_for = [&](const V& v) {
       GemmArgs b = a;
       b.nsplit = v.nsplit;
-      b.nblock = v.nblock;
-      if (v.x3) { b.A = A3; b.W = W3; b.lda = (int)lda3; b.ldw = (int)lda3; b.ldc = (int)ldc3; }
-      else { b.A = A2; b.W = W2; b.lda = (int)lda2; b.ldw = (int)lda2; b.ldc = (int)ldc2; b.wscale = scale2; b.sat_flag = flag; }
       return b;
     };
     // correctness first (the residual epilogues add to a zeroed C), then interleaved timing rounds
@@ -227,7 +181,7 @@ int main(int argc, char** argv) {
       HIP_OK(hipMemsetAsync(C, 0, cbytes, st));
       v.fn(b, st);
       HIP_OK(hipGetLastError());
-      check<<<32, 256, 0, st>>>(A, W, bias, C, sh.epi == 1 ? (v.x3 ? 3 : 2) : 0, b.ldc, M, sh.N, sh.K, chk);
+      check<<<32, 256, 0, st>>>(A, W, bias, C, sh.epi == 1 ? 2 : 0, b.ldc, M, sh.N, sh.K, chk);
       std::vector<double> h(8192 * 2);
       HIP_OK(hipMemcpyAsync(h.data(), chk, h.size() * 8, hipMemcpyDeviceToHost, st));
       HIP_OK(hipStreamSynchronize(st));
@@ -253,6 +207,7 @@ int main(int argc, char** argv) {
         printf("  %s: %d of 8192 samples off\n", v.name, bad);
       }
     }
+    int hflag;
     HIP_OK(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     std::vector<std::vector<float>> times(vs.size());
@@ -273,14 +228,38 @@ int main(int argc, char** argv) {
       std::sort(times[vi].begin(), times[vi].end());
       const float best = times[vi].front(), med = times[vi][times[vi].size() / 2];
       const double tf = 2.0 * M * sh.N * sh.K / (med * 1e-3) / 1e12;
-      const int prods = vs[vi].x3 ? 6 : 3;
-      printf("%-9s M=%d N=%d K=%d  %-30s min %7.3f med %7.3f ms  %6.1f TF/s fp32-eq (%6.1f on the pipe = %.3f of peak)  err max %.2e rms %.2e %s\n",
-             sh.name, M, sh.N, sh.K, vs[vi].name, best, med, tf, prods * tf, prods * tf / 2500.0, errs[vi], rmss[vi],
+      printf("%-9s M=%d N=%d K=%d  %-26s min %7.3f med %7.3f ms  %6.1f TF/s fp32-eq (%6.1f on the pipe = %.3f of peak)  err max %.2e rms %.2e %s\n",
+             sh.name, M, sh.N, sh.K, vs[vi].name, best, med, tf, 3 * tf, 3 * tf / 2500.0, errs[vi], rmss[vi],
              errs[vi] < 1e-5 ? "ok" : "WRONG(abl)");
+    }
+    for (const V& v : vs) {
+      if (!strstr(v.name, "stamps")) continue;
+      // the stamped build once more, alone: per-wave sums of shader cycles (s_memtime)
+      HIP_OK(hipMemsetAsync(dbg, 0, 256 * 8 * 8 * 8, st));
+      for (int i = 0; i < 20; ++i) v.fn(args_for(v), st);   // (warm clocks; every launch overwrites the same slots)
+      std::vector<unsigned long long> h(256 * 8 * 8);
+      HIP_OK(hipMemcpyAsync(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      double sd = 0, sb = 0, sk = 0, se = 0, tiles = 0, nkk = 0; int n = 0;
+      double wd[8] = {0}, wb[8] = {0};
+      for (int w = 0; w < 256 * 8; ++w) {
+        const unsigned long long* d = &h[(size_t)w * 8];
+        if (!d[4]) continue;
+        sd += (double)d[0]; sb += (double)d[1]; sk += (double)d[2]; se += (double)d[3]; tiles += (double)d[4]; nkk = (double)d[5]; ++n;
+        wd[w & 7] += (double)d[0] / d[4]; wb[w & 7] += (double)d[1] / d[4];
+      }
+      printf("%s stamps (%d waves): per tile: K loop %.0f cycles, epilogue %.0f; inside the K loop per K-step: wait for the next K-step's data %.0f, at the hand-over barrier %.0f (of %.0f per K-step)\n",
+             sh.name, n, sk / tiles, se / tiles, sd / tiles / (nkk - 1), sb / tiles / (nkk - 1), sk / tiles / nkk);
+      printf("%s stamps by wave: data wait per tile", sh.name);
+      for (int w = 0; w < 8; ++w) printf(" %.0f", wd[w] / (n / 8));
+      printf("; barrier wait per tile");
+      for (int w = 0; w < 8; ++w) printf(" %.0f", wb[w] / (n / 8));
+      printf("\n");
     }
     printf("%s: saturation flag after the runs %d\n", sh.name, hflag);
     fflush(stdout);
-    HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(A2)); HIP_OK(hipFree(W2)); HIP_OK(hipFree(A3)); HIP_OK(hipFree(W3));
+    HIP_OK(hipFree(A)); HIP_OK(hipFree(W)); HIP_OK(hipFree(A2)); HIP_OK(hipFree(W2));
+    HIP_OK(hipFree(dbg));
     HIP_OK(hipFree(C)); HIP_OK(hipFree(bias)); HIP_OK(hipFree(scale2)); HIP_OK(hipFree(flag)); HIP_OK(hipFree(chk));
   }
   return 0;
