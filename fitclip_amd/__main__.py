@@ -46,6 +46,9 @@ DEFAULTS: Dict[str, Any] = {
     "repeat_batch": False,  # train: every step sees the first batch again (overfitting smoke test)
     "labeled_clips": 32, "unlabeled_clips": 256,  # train: sizes of the two synthetic sources the mixed batches draw from
     "teacher_on_labeled": False,  # train: also run the teacher on the labeled rows (its output there is never read)
+    # precision=fp32x3: every encoder call waits for its own fp16-range flag (one host synchronisation per call) instead of
+    # leaving it to the check that evaluate / predict / train make before they use or save the embeddings
+    "strict_range": False,
 }
 
 
@@ -81,13 +84,18 @@ def instantiate(node: Any, **overrides: Any) -> Any:
 
 
 def load_encoder_config(name: str, cfg: Mapping[str, Any], device: Any = None) -> Dict[str, Any]:
-    node = yaml.safe_load((CONFIG_DIR / "encoder" / f"{name}.yaml").read_text())
+    # `encoder=<name>` picks config/encoder/<name>.yaml of the package; `encoder=<path>.yaml` a config file of the caller's (Hydra's
+    # config search path in one step: a local checkpoint, another precision, ...)
+    path = Path(name) if str(name).endswith((".yaml", ".yml")) else CONFIG_DIR / "encoder" / f"{name}.yaml"
+    node = yaml.safe_load(path.read_text())
 
     def patch(n: Any) -> None:
         if isinstance(n, dict):
             if n.get("_target_", "").endswith("load_clip_model"):
                 if cfg.get("precision"):
                     n["precision"] = cfg["precision"]
+                if cfg.get("strict_range"):
+                    n["strict_range"] = True
                 if device is not None:
                     n["device"] = str(device)  # weights go straight to the ROCm device (WiSE blends there)
             if "num_frames" in n:
@@ -203,6 +211,8 @@ def predict(cfg: Mapping[str, Any]) -> Dict[str, Any]:
                 "video": torch.from_numpy(synth.make_video(e - s, cfg["num_frames"], dims, cfg["seed"], s)).to(device),
                 "text": {"input_ids": torch.from_numpy(synth.make_text(e - s, dims, cfg["seed"], s)).to(device)},
                 "video_id": [f"clip{i}" for i in range(s, e)]}))
+    # precision fp32x3: nothing is written before the range flag of the LAST batch has been seen (FC_ERANGE raises here)
+    module.check_range()
     merged = {k: torch.cat([o[k] for o in outs]).cpu() if isinstance(outs[0][k], torch.Tensor)
               else [x for o in outs for x in o[k]] for k in outs[0]}
     torch.save(merged, cfg["output_path"])

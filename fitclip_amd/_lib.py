@@ -24,7 +24,7 @@ class FitclipHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4  # FC_ABI_VERSION of include/fitclip_hip.h
+ABI_VERSION = 5  # FC_ABI_VERSION of include/fitclip_hip.h
 
 
 class fc_config(C.Structure):
@@ -81,9 +81,10 @@ SIGNATURES = {
     "fc_split3": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "fc_gemm_split3": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fc_split2": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp]),
-    "fc_split2_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "fc_split2_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "fc_gemm_split2": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "fc_range_status": (_i32, [_vp, _vp, _i32]),
+    "fc_range_strict": (_i32, [_vp, _i32]),
     "fc_set_grad": (_i32, [_vp, C.c_char_p, _vp]),
     "fc_train_weights_bytes": (_sz, [_vp]),
     "fc_train_prepare": (_i32, [_vp, _vp, _sz, _vp]),

@@ -146,7 +146,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
     hipcc = _hipcc()
     objdir = CSRC / ("build_lab" if lab else "build_debug" if debug else "build")
     objdir.mkdir(exist_ok=True)
-    flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+    flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
              "-fvisibility=hidden", "-DFITCLIP_BUILD"] + (["-DFITCLIP_LAB"] if lab else []) + (["-DFITCLIP_DEBUG"] if debug else [])
     lib_path = LAB_LIB if lab else DEBUG_LIB if debug else LIB
     lib_path.parent.mkdir(exist_ok=True)

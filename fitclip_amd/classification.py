@@ -60,9 +60,11 @@ class VideoTextClassificationModule(VideoTextModule):
     def predict_step(self, batch: Mapping[str, Any]) -> Dict[str, Any]:
         scores = self(batch["video"])
         best = torch.from_numpy(scores.cpu().numpy().argmax(axis=-1))  # host-side report of the winning label
+        self.check_range()   # (the `.cpu()` above has drained the stream: the flag of this batch is in)
         return {"predictions": best, "labels": batch["target"][1], "video_ids": batch.get("video_id")}
 
     def validation_epoch_end(self) -> Dict[str, float]:
+        self.check_range()   # precision fp32x3: no accuracy is reported from embeddings whose fp16 planes overflowed
         ranks = torch.cat(self._ranks).cpu().numpy() if self._ranks else np.zeros(0, dtype=np.int64)
         self._ranks = []
         m = metrics_from_ranks(ranks)

@@ -78,7 +78,10 @@ class _Runtime:
 
 class CLIP(nn.Module):
     def __init__(self, dims: ClipDims = VIT_B_16, precision: str = "bf16", chunk_frames: int = 0,
-                 chunk_texts: int = 0, gemm_tile: int = 0, prune_last_block: bool = False) -> None:
+                 chunk_texts: int = 0, gemm_tile: int = 0, prune_last_block: bool = False, strict_range: bool = False) -> None:
+        """`strict_range` (precision "fp32x3" only): every `encode_image` waits for its own range flag and raises FC_ERANGE
+        itself (one host synchronisation per call, `fc_range_strict`); by default the flag is reported by the next call and
+        by `check_range()`, which every consumer of the embeddings in this package calls before it uses or saves them."""
         super().__init__()
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
@@ -86,6 +89,7 @@ class CLIP(nn.Module):
         self.precision = precision
         self.chunk_frames, self.chunk_texts, self.gemm_tile = chunk_frames, chunk_texts, gemm_tile
         self.prune_last_block = bool(prune_last_block)
+        self.strict_range = bool(strict_range)
         for name, shape in parameter_shapes(dims).items():
             *path, leaf = name.split(".")
             node: nn.Module = self
@@ -136,7 +140,7 @@ class CLIP(nn.Module):
             raise _lib.FitclipHipError(
                 f"CLIP parameters are on {dev}; move the model to the ROCm device first (no CPU fallback).")
         lib, rt = _lib.load(), self._rt
-        key = (self.precision, self.chunk_frames, self.chunk_texts, self.gemm_tile, self.prune_last_block, dev.index)
+        key = (self.precision, self.chunk_frames, self.chunk_texts, self.gemm_tile, self.prune_last_block, dev.index, self.strict_range)
         if rt.handle is None or rt.key != key:
             rt.close()
             d = self.dims
@@ -148,6 +152,8 @@ class CLIP(nn.Module):
             h = _lib._vp()
             _lib.check(lib.fc_create(cfg, h), "fc_create")
             rt.handle, rt.key = h, key
+            if self.strict_range:
+                _lib.check(lib.fc_range_strict(h, 1), "fc_range_strict")
         weights = self._named_weights()
         # (pointer, version counter) per parameter: catches re-allocation and ordinary in-place autograd-visible writes;
         # `.data` writes are announced with `invalidate_weights()`.  Inference tensors have no version counter: a model
@@ -203,7 +209,7 @@ class CLIP(nn.Module):
 
     def check_range(self, wait: bool = True) -> None:
         """precision "fp32x3" keeps the block activations as fp16 planes (|x| <= 65504): raises `FitclipHipError` (FC_ERANGE) if a
-        value beyond that was met since the weights were packed.  `wait`: synchronise with the current stream first (call it
+        value beyond that - or an infinite / NaN activation or weight - was met since the weights were packed.  `wait`: synchronise with the current stream first (call it
         after the last batch of an evaluation); without it, what the calls completed so far have shown (`encode_image`
         itself checks that on entry).  A no-op in the other precisions."""
         rt = self._rt

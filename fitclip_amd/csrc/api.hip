@@ -223,6 +223,17 @@ int debug_scan(const float* x, size_t n, hipStream_t st, const char* what) {
 #define FC_DEBUG_SCAN(x, n, st, what) do { } while (0)
 #endif
 
+// split_gemm 2: the last line of defence of the range flag.  The writers of fp16 planes test |x| <= 65504 as they go (max on
+// v_max3_f32 / fmaxf: fast, but a max drops NaN operands), and an infinity or a NaN anywhere in the blocks - an overflowed plane, a
+// NaN frame, a non-finite weight of the fp32 part of the tower - reaches the frame's embedding through LayerNorm and the
+// projections.  So every visual-tower call scans its [n, embed_dim] output (a few KB) and ORs the flag: no value leaves with rc 0.
+__global__ void __launch_bounds__(256) nonfinite_flag_kernel(const float* __restrict__ x, size_t n, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    bad |= (__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u;
+  if (bad) atomicOr(flag, 1);
+}
+
 struct Scratch {
   float* x;
   char* xn;
@@ -575,6 +586,16 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
   const int kind = h->cfg.precision;
   std::map<std::string, const void*> packed;
   size_t off = 0;
+  // split_gemm 2: the range flag (a device int behind the packed items, with a pinned host mirror) starts clear BEFORE the weights
+  // are split - a tensor with an infinite or NaN weight raises it
+  int* flag = nullptr;
+  if (h->split2()) {
+    flag = reinterpret_cast<int*>(static_cast<char*>(arena) + (fc_packed_bytes(h) - 256));
+    if (!h->sat_host && hipHostMalloc(reinterpret_cast<void**>(&h->sat_host), 64, hipHostMallocDefault) != hipSuccess)
+      return fail(FC_ENOMEM, "fc_pack_weights: cannot allocate the pinned mirror of the range flag");
+    *h->sat_host = 0;
+    if (hipMemsetAsync(flag, 0, 256, stream) != hipSuccess) return fail(FC_ELAUNCH, "fc_pack_weights: memset");
+  }
   for (auto& e : packed_list(h)) {
     const auto& slot = h->slots.at(e.name);
     void* dst = static_cast<char*>(arena) + off;
@@ -592,7 +613,7 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       const size_t img = packed_item_bytes(h, e) - 256;
       float* sc = reinterpret_cast<float*>(static_cast<char*>(dst) + img);
       FC_TRY(launch_split2_weight(slot.ptr, (long)slot.shape[1], dst, x2_row_elems(slot.shape[1]), (long)slot.shape[0],
-                                  (int)slot.shape[1], sc, stream));
+                                  (int)slot.shape[1], sc, flag, stream));
       packed[e.name + "#x2"] = dst;
       packed[e.name + "#s2"] = sc;
       off += packed_item_bytes(h, e);
@@ -637,14 +658,9 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
   fill(h->vis, "visual.transformer", h->cfg.vision_layers);
   fill(h->txt, "transformer", h->cfg.transformer_layers);
   if (h->split2()) {
-    // the range flag (device int behind the packed items, pinned host mirror) starts clear; LayerNorm outputs are bounded by
-    // sqrt(D) max|gamma| + max|beta|: a tower whose LayerNorm weights could leave fp16's range raises the flag here, once
-    h->sat_flag = reinterpret_cast<int*>(static_cast<char*>(arena) + off);
-    off += 256;
-    if (!h->sat_host && hipHostMalloc(reinterpret_cast<void**>(&h->sat_host), 64, hipHostMallocDefault) != hipSuccess)
-      return fail(FC_ENOMEM, "fc_pack_weights: cannot allocate the pinned mirror of the range flag");
-    *h->sat_host = 0;
-    if (hipMemsetAsync(h->sat_flag, 0, 256, stream) != hipSuccess) return fail(FC_ELAUNCH, "fc_pack_weights: memset");
+    // LayerNorm outputs are bounded by sqrt(D) max|gamma| + max|beta|: a tower whose LayerNorm weights could leave fp16's range
+    // (or are not finite) raises the flag here, once
+    h->sat_flag = flag;
     for (const Block& k : h->vis.blocks) {
       FC_TRY(launch_x2_ln_bound(k.ln1_w, k.ln1_b, h->cfg.vision_width, h->sat_flag, stream));
       FC_TRY(launch_x2_ln_bound(k.ln2_w, k.ln2_b, h->cfg.vision_width, h->sat_flag, stream));
@@ -722,10 +738,27 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }
+  if (h->sat_flag) {
+    const size_t total = (size_t)n * c.embed_dim;
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256)), dim3(256), 0, st, out, total, h->sat_flag);
+    FC_CHECK_LAUNCH("fc_encode_image: output scan");
+  }
   // the range flag follows the call to the host (pinned: no synchronisation; the NEXT call and fc_range_status read it)
   if (h->sat_flag && hipMemcpyAsync(h->sat_host, h->sat_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
     return fail(FC_ELAUNCH, "fc_encode_image: range flag copy");
   FC_DEBUG_SCAN(out, (size_t)n * c.embed_dim, st, "fc_encode_image");
+  if (h->sat_flag && h->strict_range) {   // fc_range_strict: THIS call answers for its own values (one host synchronisation)
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(FC_ELAUNCH, "fc_encode_image: synchronise for the range flag");
+    if (*h->sat_host)
+      return fail(FC_ERANGE, "fc_encode_image: an activation (or a weight) beyond fp16's range (65504) or not finite was met: split_gemm = 2 "
+                             "cannot represent this model's values; the embeddings of this call are not valid");
+  }
+  return FC_OK;
+}
+
+int fc_range_strict(fc_handle* h, int32_t on) {
+  if (!h) return fail(FC_EINVAL, "fc_range_strict: null handle");
+  h->strict_range = on != 0;
   return FC_OK;
 }
 
@@ -881,9 +914,10 @@ int fc_split2(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t
   if (!in || !out) return fail(FC_EINVAL, "fc_split2: null operand");
   return launch_split2_rows(in, (long)ld_in, out, (long)ld_out, (long)rows, K, sat_flag, st);
 }
-int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, float* scale2, fc_stream st) {
+int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, float* scale2, int32_t* sat_flag,
+                     fc_stream st) {
   if (!w || !out || !scale2) return fail(FC_EINVAL, "fc_split2_weight: null operand");
-  return launch_split2_weight(w, (long)ld_in, out, (long)ld_out, (long)rows, K, scale2, st);
+  return launch_split2_weight(w, (long)ld_in, out, (long)ld_out, (long)rows, K, scale2, sat_flag, st);
 }
 int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float* scale2, const float* bias, void* C, int32_t M,
                    int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, int32_t cut, fc_stream st) {

@@ -163,8 +163,10 @@ bool gemm_split2_ok(const GemmArgs& a);
 // x2 image [rows, 2 K fp16] of fp32 activation rows [rows, K] (scaled residual plane; sat_flag as in GemmArgs)
 int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int* sat_flag, hipStream_t stream);
 // x2 image of a weight tensor [rows, K] with its per-tensor power-of-two scale: scale2 <- {s, 1 / s} (two device floats), then
-// the planes of s * w (unscaled residual plane).  No host synchronisation.
-int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, hipStream_t stream);
+// the planes of s * w (unscaled residual plane).  No host synchronisation.  sat_flag (may be null): raised when the tensor holds an
+// infinite or NaN weight (it cannot be split; scale 1, the planes carry the infinities / NaNs)
+int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, int* sat_flag,
+                         hipStream_t stream);
 // raises *sat_flag when LayerNorm outputs under (gamma, beta) could leave fp16's range: sqrt(D) max|gamma| + max|beta| > 65504
 int launch_x2_ln_bound(const float* gamma, const float* beta, int D, int* sat_flag, hipStream_t stream);
 // the row cut of the fp32 pipelined kernel for an [M, N] output over K columns on the current device: 256-row panels of the head (whole tile

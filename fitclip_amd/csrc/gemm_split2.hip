@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(256) split2_rows_kernel(const float* __restric
   const long total = rows * per_row;
   const bool weight = scale2 != nullptr;
   const float s = weight ? scale2[0] : 1.f;
-  float amax = 0.f;
+  // largest |x| as a BIT PATTERN (integer order = float order for non-negative floats, and every NaN sorts above infinity: fmaxf
+  // would drop a NaN operand and the flag would stay down)
+  unsigned amax = 0u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long row = i / per_row;
     const int piece = (int)(i - row * per_row), group = piece >> 2, quarter = piece & 3;
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(256) split2_rows_kernel(const float* __restric
       split2(lo, a1, a2);
       split2(hi, b1, b2);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+      for (int e = 0; e < 4; ++e) amax = max(amax, max(__float_as_uint(lo[e]) & 0x7fffffffu, __float_as_uint(hi[e]) & 0x7fffffffu));
     }
     char* dst = out + row * ld_out_bytes + (long)group * X2_GROUP_BYTES + quarter * 16;
     auto put = [&](char* p, const f16x4& x, const f16x4& y) {
@@ -84,26 +86,34 @@ __global__ void __launch_bounds__(256) split2_rows_kernel(const float* __restric
     put(dst, a1, b1);
     put(dst + 64, a2, b2);
   }
-  if (sat_flag && !(amax <= 65504.f)) atomicOr(sat_flag, 1);
+  if (sat_flag && amax > 0x477fe000u) atomicOr(sat_flag, 1);   // 0x477fe000 = 65504.f; infinities and NaNs lie above
 }
 
-// max |w| over the tensor as the bits of a non-negative float (integer order = float order)
+// max |w| over the tensor as the bits of a non-negative float (integer order = float order; a NaN anywhere in the tensor sorts
+// above infinity and survives the reduction - fmaxf would drop it)
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ w, long ld_in, long rows, int K, unsigned* out) {
   const long per_row = K / 4, total = rows * per_row;
-  float m = 0.f;
+  unsigned m = 0u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long row = i / per_row;
     const f32x4 v = *reinterpret_cast<const f32x4*>(w + row * ld_in + (i - row * per_row) * 4);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
   }
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0u) atomicMax(out, m);
 }
-// scale2 <- {s, 1 / s}: s = 2^(14 - floor(log2 max)), i.e. max |s w| in [2^14, 2^15); an all-zero (or non-finite) tensor gets 1
-__global__ void scale_from_absmax_kernel(float* scale2) {
-  const float m = __uint_as_float(reinterpret_cast<const unsigned*>(scale2)[0]);
+// scale2 <- {s, 1 / s}: s = 2^(14 - floor(log2 max)), i.e. max |s w| in [2^14, 2^15); an all-zero tensor gets 1.  A tensor with
+// an infinite or NaN weight cannot be split: it gets 1 too, its planes hold the infinities / NaNs (loud in every product), and the
+// range flag - when the caller has one - is raised
+__global__ void scale_from_absmax_kernel(float* scale2, int* sat_flag) {
+  const unsigned bits = reinterpret_cast<const unsigned*>(scale2)[0];
+  const float m = __uint_as_float(bits);
   float s = 1.f;
-  if (m > 0.f && m < 3.0e38f) {
+  if (bits >= 0x7f800000u) {
+    if (sat_flag) atomicOr(sat_flag, 1);
+  } else if (m > 0.f) {
     int e;
     frexpf(m, &e);                            // m = f 2^e, f in [0.5, 1)  =>  floor(log2 m) = e - 1
     const int k = max(-100, min(100, 15 - e));
@@ -115,14 +125,18 @@ __global__ void scale_from_absmax_kernel(float* scale2) {
 
 // a LayerNorm output is bounded by sqrt(D) max|gamma| + max|beta| (|x - mean| / std <= sqrt(D - 1)): one wave decides
 __global__ void __launch_bounds__(64) ln_bound_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int D, int* flag) {
-  float mg = 0.f, mb = 0.f;
+  unsigned ug = 0u, ub = 0u;   // (bit patterns of |.|: a NaN sorts above infinity instead of being dropped by fmaxf)
   for (int i = threadIdx.x; i < D; i += 64) {
-    mg = fmaxf(mg, fabsf(gamma[i]));
-    mb = fmaxf(mb, fabsf(beta[i]));
+    ug = max(ug, __float_as_uint(gamma[i]) & 0x7fffffffu);
+    ub = max(ub, __float_as_uint(beta[i]) & 0x7fffffffu);
   }
-  mg = wave_max(mg);
-  mb = wave_max(mb);
-  if (threadIdx.x == 0 && !(sqrtf((float)D) * mg + mb <= 65504.f)) atomicOr(flag, 1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ug = max(ug, (unsigned)__shfl_xor((int)ug, o, 64));
+    ub = max(ub, (unsigned)__shfl_xor((int)ub, o, 64));
+  }
+  const float mg = __uint_as_float(ug), mb = __uint_as_float(ub);
+  if (threadIdx.x == 0 && !(sqrtf((float)D) * mg + mb <= 65504.f)) atomicOr(flag, 1);   // (false for a NaN or an infinity too)
 }
 
 }  // namespace
@@ -187,7 +201,8 @@ int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long
   return FC_OK;
 }
 
-int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, hipStream_t stream) {
+int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, int* sat_flag,
+                         hipStream_t stream) {
   if (rows <= 0) return FC_OK;
   if (int rc = check_rows("split2_weight", w, ld_in, out, ld_out, K)) return rc;
   if (!scale2 || ((uintptr_t)scale2 & 7)) return fail(FC_EINVAL, "split2_weight: scale pair missing or unaligned");
@@ -195,7 +210,7 @@ int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, lon
   const long total4 = rows * (K / 4);
   hipLaunchKernelGGL(absmax_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 2048)), dim3(256), 0, stream, w, ld_in, rows, K,
                      reinterpret_cast<unsigned*>(scale2));
-  hipLaunchKernelGGL(scale_from_absmax_kernel, dim3(1), dim3(1), 0, stream, scale2);
+  hipLaunchKernelGGL(scale_from_absmax_kernel, dim3(1), dim3(1), 0, stream, scale2, sat_flag);
   const long total = rows * (K / 8);
   hipLaunchKernelGGL(split2_rows_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, stream, w, ld_in,
                      static_cast<char*>(out), ld_out * 2, rows, K, (const float*)scale2, (int*)nullptr);

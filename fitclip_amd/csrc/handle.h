@@ -47,6 +47,7 @@ struct fc_handle {
   // (copied behind every visual-tower call; allocated by fc_pack_weights, freed by fc_destroy)
   int* sat_flag = nullptr;
   int* sat_host = nullptr;
+  bool strict_range = false;  // fc_range_strict: fc_encode_image waits for its own flag copy and returns FC_ERANGE itself
   // training
   bool train_ready = false;
   const float* zeros = nullptr;  // >= 16 KiB of zeros in the training weight arena (null bias / TN tail rows)

@@ -205,17 +205,20 @@ def split2(x: torch.Tensor, flag: Optional[torch.Tensor] = None) -> torch.Tensor
     return out
 
 
-def split2_weight(w: torch.Tensor):
+def split2_weight(w: torch.Tensor, flag: Optional[torch.Tensor] = None):
     """(x2 rows [N, 2 K], scale pair float32 [2] = {s, 1 / s}) of a WEIGHT [N, K] (fc_split2_weight): s the power of two that
-    puts max |s w| into [2^14, 2^15); g1 = fp16(s w), g2 = fp16(s w - g1).  Operand pair of `gemm_split2`."""
+    puts max |s w| into [2^14, 2^15); g1 = fp16(s w), g2 = fp16(s w - g1).  Operand pair of `gemm_split2`.  `flag` (int32 [1],
+    optional): 1 is ORed in when the tensor holds an infinite or NaN weight."""
     _dev(w, "w", torch.float32)
+    if flag is not None:
+        _dev(flag, "flag", torch.int32)
     if w.dim() != 2 or w.shape[1] % 32:
         raise ValueError("split2_weight needs [N, K] with K a multiple of 32")
     out = _x2_empty(w.shape[0], w.shape[1], w.device)
     scale = torch.empty(2, dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         _lib.check(_lib.load().fc_split2_weight(w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), w.shape[0], w.shape[1],
-                                                scale.data_ptr(), _lib.current_stream()), "fc_split2_weight")
+                                                scale.data_ptr(), _ptr(flag), _lib.current_stream()), "fc_split2_weight")
     return out, scale
 
 

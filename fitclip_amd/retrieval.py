@@ -54,6 +54,16 @@ class VideoTextModule:
         encoded_video, encoded_text = self(dict(batch))
         return {"encoded_videos": encoded_video, "encoded_texts": encoded_text, "video_ids": video_ids}
 
+    def check_range(self) -> None:
+        """precision "fp32x3": raises FC_ERANGE if any encoder call of this module so far met a value its fp16 planes cannot hold
+        (`CLIP.check_range`; one host synchronisation).  Every path that hands embeddings out - `validation_epoch_end`, the
+        classification module's, `command=predict` before it saves, the training step with a split-mode teacher - calls it
+        first.  A no-op for the other precisions and for encoders without the method."""
+        for enc in (self.encoder, getattr(self, "teacher", None)):
+            model = getattr(enc, "model", None)
+            if hasattr(model, "check_range"):
+                model.check_range()
+
 
 class TextVideoRetrievalModule(VideoTextModule):
     """`gather_batches` chooses what `loss/val` means on more than one rank (the retrieval metrics do not depend on it):
@@ -100,9 +110,7 @@ class TextVideoRetrievalModule(VideoTextModule):
     def validation_epoch_end(self) -> Dict[str, float]:
         """cat all batches, scores = T @ V^T, target = arange, R@1/5/10 + median rank
         (text_video_retrieval.py:67-83); the scores only ever exist tile by tile inside `fc_similarity_ranks`."""
-        model = getattr(self.encoder, "model", None)
-        if hasattr(model, "check_range"):
-            model.check_range()   # precision fp32x3: an activation beyond fp16's range since the weights were packed is an error
+        self.check_range()   # precision fp32x3: an activation beyond fp16's range since the weights were packed is an error
         encoded_videos = torch.cat([o[0] for o in self._outputs])
         encoded_texts = torch.cat([o[1] for o in self._outputs])
         rank, world_size = D.world()

@@ -543,6 +543,11 @@ class TeacherStudentTrainer(TeacherStudentModule):
 
     def fit_step(self, batch: Mapping[str, Any]) -> float:
         loss = self.training_step_end(self.training_step(batch))
+        # a frozen teacher in precision fp32x3: its embeddings fed this loss - no gradient is applied if its fp16 planes
+        # overflowed (FC_ERANGE raises here; `training_step_end` has synchronised with the stream already)
+        teacher_model = getattr(self.teacher, "model", None)
+        if getattr(teacher_model, "precision", None) == "fp32x3":
+            teacher_model.check_range()
         self.backward()
         self.optimizer_step()
         return loss

@@ -41,7 +41,7 @@ typedef enum {
   FC_ELAUNCH = -2, /* HIP launch / runtime error */
   FC_ENOMEM = -3,  /* workspace or arena too small */
   FC_ESTATE = -4,  /* call order (weights missing / not packed) */
-  FC_ERANGE = -5   /* split_gemm = 2: an activation (or LayerNorm weights) beyond fp16's range was met - results not valid */
+  FC_ERANGE = -5   /* split_gemm = 2: an activation (or a weight) beyond fp16's range, or not finite, was met - results not valid */
 } fc_status;
 
 typedef enum {
@@ -50,7 +50,7 @@ typedef enum {
 } fc_precision;
 
 /* ABI revision of this header: bumped whenever a struct or a signature changes; the tail of fc_version() names it. */
-#define FC_ABI_VERSION 4
+#define FC_ABI_VERSION 5
 
 /* Architecture: the keys of config/encoder/clip_from_scratch_vit_b_16.yaml:5-16 (heads = width / 64 as in
  * clip.model.CLIP).  Head dimension must be 64.
@@ -84,8 +84,11 @@ typedef struct {
                                  fp32 path.  2: the same GEMMs on the fp16 matrix cores over TWO-plane operands ("x2" rows,
                                  fc_split2: x = h1 + 2^-11 h2 in fp16) with THREE products per fp32 product
                                  (fc_gemm_split2) - fp32 accuracy at ~2.7x the fp32-MFMA rate.  fp16 planes hold
-                                 |x| <= 65504: a value beyond that raises a device-side flag and the NEXT fc_encode_image
-                                 (and fc_range_status) returns FC_ERANGE - never silently wrong.
+                                 |x| <= 65504: a value beyond that (or an infinite / NaN value or weight) raises a device-side
+                                 flag and the NEXT fc_encode_image (and fc_range_status) returns FC_ERANGE.  A caller MUST ask
+                                 fc_range_status(wait = 1) after its last batch before it uses or saves the embeddings - or
+                                 switch fc_range_strict on, and every fc_encode_image answers for itself (one host
+                                 synchronisation per call) - never silently wrong.
                                  0 (default): fp32-input MFMA everywhere */
 } fc_config;
 #define FC_CONFIG_INIT {(int32_t)sizeof(fc_config)}
@@ -127,6 +130,10 @@ FC_API int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n_texts, flo
  * first waits for the work queued on `stream` (one host synchronisation - call it after the last batch of an evaluation);
  * wait == 0: what the flag copies of the calls completed so far have shown (fc_encode_image itself checks this on entry). */
 FC_API int fc_range_status(fc_handle* h, fc_stream stream, int32_t wait);
+/* on != 0: every fc_encode_image of a split_gemm = 2 handle waits for its own range flag before it returns (one host
+ * synchronisation per call; not capturable into a hipGraph) and returns FC_ERANGE ITSELF when its values left fp16's range.
+ * Off by default: the flag is then reported by the NEXT fc_encode_image and by fc_range_status. */
+FC_API int fc_range_strict(fc_handle* h, int32_t on);
 
 /* Eval transform on the device (clip_video_text_encoder.py:125-133): frames dev uint8 [n, H, W, 3]
  * -> out dev f32 [n, 3, R, R] = normalise(center_crop(bicubic_resize(frames / 255, shorter side R), R)).  mean3 / std3
@@ -225,16 +232,19 @@ FC_API int fc_gemm_split3(int32_t epilogue, const void* A3, const void* W3, cons
 /* Two-plane fp16 operands ("x2" rows, split_gemm = 2): fp32 rows [rows, K] -> h1 = fp16(x), h2 = fp16((x - h1) 2^11), i.e.
  * x = h1 + 2^-11 h2 to 2^-23 |x| for |x| in [2^-14, 65504] (2^-36 absolute below).  Every 32 columns become one 128-byte line
  * [h1 x32 | h2 x32]; a row is 2 K fp16 positions = the bytes of the fp32 row (ld_out counts fp16 positions, a multiple of 64;
- * `out` 128-byte aligned).  K % 32 == 0.  sat_flag (may be null): device int, 1 is ORed in when |x| > 65504 was met. */
+ * `out` 128-byte aligned).  K % 32 == 0.  sat_flag (may be null): device int, 1 is ORed in when |x| > 65504, an infinity or a NaN
+ * was met. */
 FC_API int fc_split2(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, int32_t* sat_flag,
               fc_stream stream);
 /* ... of a WEIGHT tensor [rows, K]: scale2 (two device floats) <- {s, 1 / s} with s the power of two that puts max |s w| into
- * [2^14, 2^15), then g1 = fp16(s w), g2 = fp16(s w - g1) (unscaled residual) in the same line layout.  No host synchronisation. */
+ * [2^14, 2^15), then g1 = fp16(s w), g2 = fp16(s w - g1) (unscaled residual) in the same line layout.  No host synchronisation.
+ * sat_flag (may be null): device int, 1 is ORed in when the tensor holds an infinite or NaN weight (it cannot be split: scale 1,
+ * the planes carry the infinities / NaNs into every product). */
 FC_API int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int32_t K, float* scale2,
-                     fc_stream stream);
+                     int32_t* sat_flag, fc_stream stream);
 /* C = epilogue((A . W^T) / s) over x2 operands A2 [M, K] (fc_split2, LayerNorm kind 4, attention precision 5, epilogue 10) and
  * W2 [N, K] (fc_split2_weight, with its scale2): the three fp16 products h1 g1 + h1 g2 + h2 (2^-11 g1) of every fp32 product
- * on v_mfma_f32_32x32x16_f16, accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-22 per product.
+ * on v_mfma_f32_16x16x32_f16, accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-22 per product.
  * epilogue 6: C fp32 [M, N] = acc + bias; 8: C fp32 += acc + bias in place; 10: C x2 rows [M, 2 N fp16] =
  * planes(QuickGELU(acc + bias)) (sat_flag as in fc_split2).  K % 64 == 0, K >= 128, N % 32 == 0; operands below 4 GiB.
  * `cut`: the tile height of the persistent kernel - 0: 256 rows, or 128 when there are fewer 256-row tiles than compute units

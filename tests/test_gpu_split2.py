@@ -459,6 +459,150 @@ def test_attention_operands_beyond_fp16_raise_too(vitb16_state_dict):
         hot.check_range()
 
 
+def _copy_sd(sd):
+    return {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v.clone()) for k, v in sd.items()}
+
+
+def _hot_sd(sd):
+    """QuickGELU(1e5) = 1e5 in block 1: an activation no fp16 plane can hold, at run time."""
+    hot = _copy_sd(sd)
+    hot["visual.transformer.resblocks.1.mlp.c_fc.bias"] = hot["visual.transformer.resblocks.1.mlp.c_fc.bias"] + 1.0e5
+    return hot
+
+
+def test_nan_and_infinity_raise_the_flag_like_an_overflow(tiny_state_dict):
+    """A running maximum drops NaN operands (`fmaxf`, `v_max3_f32`): the range tests look at bit patterns / at the planes, and every
+    visual-tower call scans its embeddings - a NaN or infinite activation or weight is FC_ERANGE, not rc 0."""
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x = torch.randn(64, 256, device=DEV)
+    ops.split2(x, flag=flag)
+    assert int(flag) == 0
+    for poison in (float("nan"), float("inf"), -float("inf"), 7.0e4):
+        y = x.clone()
+        y[17, 33] = poison
+        flag.zero_()
+        ops.split2(y, flag=flag)
+        assert int(flag) == 1, poison
+    w = torch.randn(96, 128, device=DEV)
+    flag.zero_()
+    _, sc = ops.split2_weight(w, flag=flag)
+    assert int(flag) == 0 and sc[0] * sc[1] == 1
+    for poison in (float("nan"), float("inf")):
+        v = w.clone()
+        v[5, 7] = poison
+        flag.zero_()
+        w2, sc = ops.split2_weight(v, flag=flag)
+        assert int(flag) == 1 and sc.tolist() == [1.0, 1.0], poison        # no scale can be chosen: 1, and the flag
+        assert not bool(torch.isfinite(ops.x2_planes(w2)[0].float()).all())  # the planes carry it: loud in every product
+    # the QuickGELU epilogue tests the planes it writes: a NaN pre-activation (NaN bias) raises the flag as an overflow does
+    a2 = ops.split2(torch.randn(300, 256, device=DEV))
+    w2, sc = ops.split2_weight(torch.randn(128, 256, device=DEV) / 16)
+    for poison, want in ((float("nan"), 1), (1.0e5, 1), (0.0, 0)):
+        bias = torch.zeros(128, device=DEV)
+        bias[3] = poison
+        flag.zero_()
+        ops.gemm_split2(a2, w2, sc, bias, ops.EPI_GELU_X2, flag=flag)
+        assert int(flag) == want, poison
+    d = synth.TINY
+    frames = torch.from_numpy(synth.make_video(2, 2, d, seed=9)).reshape(-1, 3, d.image_resolution, d.image_resolution).to(DEV)
+    # a NaN weight of a block GEMM (flag at pack time), of the fp32 part of the tower and a NaN pixel (flag from the output scan)
+    for key in ("visual.transformer.resblocks.0.mlp.c_fc.weight", "visual.conv1.weight", "visual.ln_post.weight", None):
+        sd = _copy_sd(tiny_state_dict)
+        f = frames.clone()
+        if key is None:
+            f[1, 2, 5, 5] = float("nan")
+        else:
+            t = torch.as_tensor(sd[key]).clone()
+            t.view(-1)[3] = float("nan")
+            sd[key] = t
+        model = build_clip(sd, precision="fp32x3", device=DEV)
+        model.encode_image(f)
+        with pytest.raises(_lib.FitclipHipError, match="fp16"):
+            model.check_range()
+
+
+def test_strict_range_makes_every_call_answer_for_itself(tiny_state_dict):
+    """`strict_range=True` (fc_range_strict): the call whose activations left fp16's range raises FC_ERANGE ITSELF."""
+    d = synth.TINY
+    frames = torch.from_numpy(synth.make_video(2, 2, d, seed=9)).reshape(-1, 3, d.image_resolution, d.image_resolution).to(DEV)
+    ok = build_clip(tiny_state_dict, precision="fp32x3", device=DEV, strict_range=True)
+    lazy = build_clip(tiny_state_dict, precision="fp32x3", device=DEV)
+    assert torch.equal(ok.encode_image(frames), lazy.encode_image(frames))
+    hot = build_clip(_hot_sd(tiny_state_dict), precision="fp32x3", device=DEV, strict_range=True)
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.encode_image(frames)
+    deferred = build_clip(_hot_sd(tiny_state_dict), precision="fp32x3", device=DEV)
+    deferred.encode_image(frames)                                  # default: rc 0 here ...
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        deferred.check_range()                                     # ... and the consumer's check raises
+
+
+def test_predict_saves_nothing_when_the_last_batch_left_fp16s_range(tmp_path, tiny_state_dict, capsys):
+    """`command=predict` (aligner/__main__.py:70-91) writes its file only after the range flag of the LAST batch has been seen."""
+    import yaml
+    from fitclip_amd.__main__ import main
+
+    def config(name, sd):
+        torch.save({k: torch.as_tensor(v) for k, v in sd.items()}, tmp_path / f"{name}.pt")
+        path = tmp_path / f"{name}.yaml"
+        path.write_text(yaml.safe_dump({"_target_": "fitclip_amd.encoder.ClipVideoTextEncoder", "num_frames": 2, "bpe_path": None,
+                                        "model": {"_target_": "fitclip_amd.clip_model.load_clip_model", "name": str(tmp_path / f"{name}.pt"),
+                                                  "precision": "fp32x3"}}))
+        return path
+
+    out = tmp_path / "ok.out.pt"
+    main(["command=predict", f"encoder={config('ok', tiny_state_dict)}", "n_clips=3", "num_frames=2", "eval_batch_size=2", f"output_path={out}"])
+    capsys.readouterr()
+    assert torch.load(out)["encoded_videos"].shape == (3, synth.TINY.embed_dim)
+    bad = tmp_path / "hot.out.pt"
+    for extra in ([], ["strict_range=true"]):
+        with pytest.raises(_lib.FitclipHipError, match="fp16"):
+            main(["command=predict", f"encoder={config('hot', _hot_sd(tiny_state_dict))}", "n_clips=3", "num_frames=2", "eval_batch_size=2",
+                  f"output_path={bad}", *extra])
+        assert not bad.exists()
+
+
+def test_classification_reports_no_accuracy_from_out_of_range_embeddings(tiny_state_dict):
+    """`VideoTextClassificationModule.validation_epoch_end` / `predict_step` (aligner/video_text_classification.py:86-118)."""
+    from fitclip_amd.classification import VideoTextClassificationModule
+    d = synth.TINY
+    labels, video = ["cat", "dog", "guitar"], torch.from_numpy(synth.make_video(4, 2, d, seed=4)).to(DEV)
+    target = (None, torch.arange(4) % 3)
+    ok = VideoTextClassificationModule(ClipVideoTextEncoder(build_clip(tiny_state_dict, precision="fp32x3", device=DEV)), labels)
+    ok.validation_step({"video": video, "target": target})
+    assert set(ok.validation_epoch_end()) == {"a1", "a5", "mr"}
+    hot = VideoTextClassificationModule(ClipVideoTextEncoder(build_clip(_hot_sd(tiny_state_dict), precision="fp32x3", device=DEV)), labels)
+    hot.validation_step({"video": video, "target": target})
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.validation_epoch_end()
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.predict_step({"video": video, "target": target})
+
+
+def test_no_gradient_step_from_an_out_of_range_fp32x3_teacher(tiny_state_dict):
+    """`TeacherStudentTrainer.fit_step` with a frozen teacher in precision fp32x3 (teacher_student.py:93-96): FC_ERANGE before the
+    backward, the student's parameters untouched."""
+    from fitclip_amd.training import TeacherStudentTrainer
+    d = synth.TINY
+    student_np = synth.perturbed_state_dict(tiny_state_dict, d, seed=5, rel=0.3)
+    video, ids = torch.from_numpy(synth.make_video(8, 2, d, seed=30)).to(DEV), torch.from_numpy(synth.make_text(8, d, seed=30)).to(DEV)
+    batch = {"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video, "text_teacher": {"input_ids": ids},
+             "dataset": ["labeled"] * 4 + ["unlabeled"] * 4}
+
+    def trainer(teacher_sd):
+        student = ClipVideoTextEncoder(build_clip(student_np, precision="fp32", device=DEV))
+        teacher = ClipVideoTextEncoder(build_clip(teacher_sd, precision="fp32x3", device=DEV))
+        return TeacherStudentTrainer(student, teacher, init_temperature=0.05, lr=1e-4)
+
+    ok = trainer(tiny_state_dict)
+    assert np.isfinite(ok.fit_step(dict(batch)))
+    hot = trainer(_hot_sd(tiny_state_dict))
+    before = {k: v.clone() for k, v in hot.student.model.state_dict().items()}
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.fit_step(dict(batch))
+    assert all(torch.equal(v, before[k]) for k, v in hot.student.model.state_dict().items())
+
+
 def test_gemm_split2_race_screen():
     """Counted vmcnt waits, one barrier per K-step, two LDS stages, pieces spread over MFMA groups, half-pass output patches: a
     misplaced wait shows as rare wrong tiles.  20 rounds of a multi-round shape (ragged last panel, all three epilogues) must

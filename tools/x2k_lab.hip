@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
     fill_f32<<<2048, 256, 0, st>>>(A, (size_t)M * sh.K, 1u, a_scale);
     fill_f32<<<2048, 256, 0, st>>>(W, (size_t)sh.N * sh.K, 2u, w_mul * 2.0f / sqrtf((float)sh.K));
     fill_f32<<<64, 256, 0, st>>>(bias, sh.N, 3u, 0.5f);
-    if (launch_split2_rows(A, sh.K, A2, lda2, M, sh.K, flag, st) || launch_split2_weight(W, sh.K, W2, lda2, sh.N, sh.K, scale2, st)) return 3;
+    if (launch_split2_rows(A, sh.K, A2, lda2, M, sh.K, flag, st) || launch_split2_weight(W, sh.K, W2, lda2, sh.N, sh.K, scale2, nullptr, st)) return 3;
     GemmArgs a{};
     a.bias = bias; a.C = C; a.alpha = 1.f;
     a.M = M; a.N = sh.N; a.K = sh.K;
