@@ -71,7 +71,9 @@ def test_weight_scale_is_the_power_of_two_that_fills_the_range():
     assert zs.tolist() == [1.0, 1.0] and not z2.any()
 
 
-@pytest.mark.parametrize("M,N,K", [(20000, 768, 768), (16389, 2304, 768), (12345, 768, 3072), (300, 512, 128), (70000, 3072, 256)])
+@pytest.mark.parametrize("M,N,K", [(20000, 768, 768), (16389, 2304, 768), (12345, 768, 3072), (300, 512, 128), (70000, 3072, 256),
+                                   # ViT-L/14's block shapes (width 1024, 257 tokens; config/encoder/clip_vit_l_14.yaml of the reference)
+                                   (16448, 1024, 1024), (16448, 3072, 1024), (8224, 4096, 1024), (8224, 1024, 4096)])
 def test_three_product_gemm_has_fp32_accuracy(M, N, K):
     """fc_gemm_split2 against a float64 product of the same fp32 operands: as accurate as the fp32-input MFMA kernel; whole
     tiles and ragged last row panels, more tiles than CUs (the prefetch across the tile boundary), the shortest K."""
@@ -133,7 +135,8 @@ def test_residual_epilogue_is_the_bias_epilogue_plus_the_stream(M, N, K):
 
 
 @pytest.mark.parametrize("epi", ["bias", "resid", "gelu"])
-@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 2304, 768), (25216, 768, 3072), (7000, 3072, 768), (130, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 2304, 768), (25216, 768, 3072), (7000, 3072, 768), (130, 768, 768),
+                                   (6425, 1024, 1024), (6425, 4096, 1024), (6425, 1024, 4096)])   # 25 frames of ViT-L/14
 def test_tile_height_is_bit_invisible(M, N, K, epi):
     """Launches with fewer 256-row tiles than CUs run on 128-row tiles (twice the busy CUs): an element sees the same K order and
     the same product chain whatever tile holds it, so the automatic choice, 256-row and 128-row tiles give the same bits."""
