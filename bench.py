@@ -205,7 +205,7 @@ def load_traffic(precision, shape, epilogue):
     from fitclip_amd.build import source_fingerprint
     fp = source_fingerprint()
     seen = []
-    for name in (f"traffic_r05_{precision}.json", f"traffic_r05_{precision}_c3.json", f"traffic_r04_{precision}.json", f"traffic_r04_{precision}_c3.json", f"traffic_r03_{precision}.json",
+    for name in (f"traffic_r06_{precision}.json", f"traffic_r06_{precision}_c3.json", f"traffic_r05_{precision}.json", f"traffic_r05_{precision}_c3.json", f"traffic_r04_{precision}.json", f"traffic_r04_{precision}_c3.json", f"traffic_r03_{precision}.json",
                  f"traffic_r02_{precision}.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.exists(path):
@@ -445,12 +445,12 @@ SPLIT_MODES = {
     "fp32x3": (3, 2, {6: "bias_f32_out", 10: "bias_quickgelu_x2_out", 8: "bias_residual_f32_out"}, "fp16",
                "gemm_split2_kernel<256x256><two fp16 planes per operand, three MFMA products per fp32 product, {epi}>",
                "fp32 values as two fp16 numbers (x = h1 + 2^-11 h2; weights with a power-of-two scale per tensor); three fp16 MFMA "
-               "products per fp32 product, fp32 accumulate (the visual tower's block GEMMs); the attention products as six bf16 "
-               "products; LayerNorm, softmax arithmetic, residual stream, patch embedding and the text tower in plain fp32"),
+               "products per fp32 product, fp32 accumulate (the visual tower's block GEMMs); its attention products: {attention}; "
+               "LayerNorm, softmax arithmetic, residual stream, patch embedding and the text tower in plain fp32"),
     "fp32x6": (6, 1, {6: "bias_f32_out", 7: "bias_quickgelu_x3_out", 8: "bias_residual_f32_out"}, "bf16",
                "gemm_split3_kernel<256x256><three bf16 planes per operand, six MFMA products per fp32 product, {epi}>",
                "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate (the visual "
-               "tower's block GEMMs and attention products); LayerNorm, softmax arithmetic, residual stream, patch "
+               "tower's block GEMMs); its attention products: {attention}; LayerNorm, softmax arithmetic, residual stream, patch "
                "embedding and the text tower in plain fp32"),
 }
 
@@ -498,7 +498,8 @@ def run_split_mode(sd, video, text, args, shards, device, backend, precision="fp
     return {
         "precision": precision,
         "value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": dtype,
+        "dtype": dtype.format(attention=attention_description(
+            records, (enc.model.dims.image_resolution // enc.model.dims.vision_patch_size) ** 2 + 1)),
         "roofline": {"bound": "mfma", "kernel": kernel_fmt.format(epi=epi_name) + f" M={M} N={N} K={K6 // nprod} (x {nprod} products)",
                      "achieved": round(pipe_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS[pipe], "unit": "TFLOP/s",
                      "frac": round(pipe_flops * cnt / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[pipe], 4),
@@ -560,6 +561,39 @@ CONFIG_DEFAULTS = {  # BASELINE.json `configs`: index, clips, frames, scaling
 }
 
 
+def metric_name(config: str, frames: int) -> str:
+    """The line's `metric`: BASELINE.json's metric with the frame count of the configuration that RAN (c2 at its default 8 frames is
+    BASELINE's string verbatim; c4 is a 16-frame workload, c3 a 4-frame one, and `--frames` changes any of them)."""
+    through = {"c2": "", "c4": "", "c3": " through command=evaluate, encoder=wise", "c5": " through the KD training step"}[config]
+    return f"video-text pairs/sec{through} ({frames}-frame 224^2, 77-tok)"
+
+
+def plan_shards(args, world: int):
+    """(clips per rank, clips per encoder call) of a run: c2 is weak scaling (`--clips` per rank), the others shard `total_clips`
+    exactly and contiguously (`distributed.shard_counts`: ragged when the world does not divide the total)."""
+    from fitclip_amd import distributed as D
+    conf = CONFIG_DEFAULTS[args.config]
+    if args.config == "c2":
+        return [args.clips] * world, None
+    total = args.total_clips or conf["total_clips"]
+    if total < world:
+        raise SystemExit(f"--config {args.config}: {total} clips cannot be sharded over {world} ranks")
+    return D.shard_counts(total, world), args.eval_batch or conf.get("eval_batch")
+
+
+ATTENTION_FORMS = {  # fc_prof_record.epilogue of an attention record (include/fitclip_hip.h) -> what the kernel computes with
+    0: "fp32-input MFMA", 1: "bf16 MFMA", 3: "fp32-input MFMA (three-plane rows out)", 4: "six bf16 MFMA products per fp32 product",
+    5: "six bf16 MFMA products per fp32 product", 6: "three fp16 MFMA products per fp32 product"}
+
+
+def attention_description(records, tokens: int) -> str:
+    """Which arithmetic the visual tower's attention launches (sequences of `tokens` tokens) of an instrumented step ran, from the
+    library's own records."""
+    forms = sorted({(r["epilogue"], r["tile"]) for r in records if r["kind"] == 1 and r["K"] == tokens})
+    return " / ".join(ATTENTION_FORMS.get(code, f"code {code}") + (" + a split pass over its fp32 output" if split_pass else "")
+                      for code, split_pass in forms) or "none recorded"
+
+
 def fill_video(n_clips, frames, res, seed, device, block=256):
     """`synth_video_on_device` in blocks of clips (the generator's temporaries stay small next to a 79 GB shard)."""
     out = torch.empty((n_clips, frames, 3, res, res), dtype=torch.float32, device=device)
@@ -592,6 +626,32 @@ def run_kd_config(sd, dims, args, shards, device, backend):
     n_lab = n // 2
     batch = {"video_student": video, "text_student": {"input_ids": ids}, "video_teacher": video,
              "text_teacher": {"input_ids": ids}, "dataset": ["labeled"] * n_lab + ["unlabeled"] * (n - n_lab)}
+    # BASELINE configs[4] AS WRITTEN - "teacher+student dual forward with KD-loss similarity compute" - is the forward half of the
+    # step: both models over the whole local batch (teacher_student.py:93-96), the packed gather of the four embedding matrices,
+    # NCE on the labeled rows and KD on the unlabeled ones (teacher_student.py:142-173); no backward, nothing kept.  Its own number:
+    from fitclip_amd.retrieval import TeacherStudentModule
+    fwd = TeacherStudentModule(student, teacher, init_temperature=0.05)
+
+    def forward_only():
+        (sv, st), (tv, tt) = fwd.step(batch)
+        labeled = fwd.dataset_step_end(((sv[:n_lab], st[:n_lab]), (tv[:n_lab], tt[:n_lab])), labeled=True)
+        unlabeled = fwd.dataset_step_end(((sv[n_lab:], st[n_lab:]), (tv[n_lab:], tt[n_lab:])), labeled=False)
+        return labeled, unlabeled
+
+    for _ in range(args.warmup):
+        forward_only()
+    fwd_elapsed, fwd_losses = timed_steps(forward_only, args.steps, device, backend)
+    fwd_flops = 2.0 * max(shards.counts) * (frames * GF_PER_FRAME + GF_PER_TEXT)
+    kd_forward = {"value": round(shards.n_total * args.steps / fwd_elapsed, 2), "unit": "pairs/s",
+                  "ms_per_step": round(fwd_elapsed / args.steps * 1e3, 3),
+                  "workload": "teacher + student forward over the whole batch (no activations kept), one packed all-gather of the four "
+                              "embedding matrices, NCE (labeled half) + KD (unlabeled half) loss values - BASELINE configs[4] as written; "
+                              "the line's `value` is the full training step (forward + backward + AdamW)",
+                  "tflops": round(fwd_flops * args.steps / fwd_elapsed / 1e12, 2),
+                  "frac_of_fp32_mfma_peak": round(fwd_flops * args.steps / fwd_elapsed / 1e12 / PEAK_TFLOPS["fp32"], 4),
+                  "losses": [round(float(x), 6) for x in fwd_losses]}
+    del fwd
+    torch.cuda.empty_cache()
     # A rank's share keeps 116 MB of activations per frame (nothing is recomputed): 64 clips x 8 frames = 65 GB fit, the 512 or
     # 256 clips of one or two ranks do not.  The step is then SPLIT (training.py: split_step): as many clips as fit next to one
     # micro-batch keep their activations, the others are forwarded without them and re-forwarded micro-batch by micro-batch in
@@ -618,7 +678,7 @@ def run_kd_config(sd, dims, args, shards, device, backend):
                             "note": "activations of the whole share do not fit: gradient-cache schedule, one more student "
                                     "forward over the clips that were not kept (counted in executed_flops_per_step only)"}
                            if keep < n else None),
-            "losses": [round(float(x), 6) for x in losses],
+            "losses": [round(float(x), 6) for x in losses], "kd_forward": kd_forward,
             "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
@@ -816,13 +876,24 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_run:
+        # launcher, rendezvous and shard plumbing on the CPU: every rank derives its shard with the code the real run uses and the
+        # plans meet on rank 0 through a collective (what an N-rank line would print about its sharding, without the GPU)
         total = torch.tensor([float(rank)])
+        counts, eval_batch = plan_shards(args, world)
+        mine = Shards(counts, rank, eval_batch)
+        calls = 1 if mine.eval_batch is None else -(-mine.n_local // mine.eval_batch)
+        plans = [[mine.rank, mine.offset, mine.n_local, calls]]
         if world > 1:
             dist.init_process_group("gloo")
             dist.all_reduce(total)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, plans[0])
+            plans = gathered
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "sum_of_ranks": float(total)}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "sum_of_ranks": float(total), "config": args.config,
+                              "metric": metric_name(args.config, args.frames), "frames": args.frames, "scaling": conf["scaling"],
+                              "n_total": mine.n_total, "shards [rank, first clip, clips, encoder calls]": plans}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -845,28 +916,19 @@ def main() -> None:
 
     dims = synth.VIT_B_16
     sd = synth.make_state_dict(dims, seed=42)
-    if args.config == "c2":
-        counts = [args.clips] * world
-        eval_batch = None
-    else:
-        total = args.total_clips or conf["total_clips"]
-        if total < world:
-            raise SystemExit(f"--config {args.config}: {total} clips cannot be sharded over {world} ranks")
-        counts = D.shard_counts(total, world)
-        eval_batch = args.eval_batch or conf.get("eval_batch")
+    counts, eval_batch = plan_shards(args, world)
     shards = Shards(counts, rank, eval_batch)
     n_local, n_total = shards.n_local, shards.n_total
     sharding = (f"{n_total} clips in exact contiguous shards {counts if len(set(counts)) > 1 else f'of {counts[0]}'} over {world} "
                 f"rank(s)")
-    base = {"metric": "video-text pairs/sec (8-frame 224^2, 77-tok)", "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+    base = {"metric": metric_name(args.config, args.frames), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "higher_is_better": True, "scaling": conf["scaling"], "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic"}
     collectives = f"{args.backend} process group, {world} rank(s)" if grouped else "none (single process)"
 
     if args.config == "c5":
         kd = run_kd_config(sd, dims, args, shards, device, args.backend)
-        result = {**base, "metric": "video-text pairs/sec through the KD training step (8-frame 224^2, 77-tok)",
-                  "value": kd["value"], "ms_per_step": kd["ms_per_step"],
+        result = {**base, "value": kd["value"], "ms_per_step": kd["ms_per_step"],
                   "config": {"workload": f"KD training step, teacher + student CLIP ViT-B/16 dual forward, {n_total} clips x "
                                          f"{args.frames} frames x 224^2 + {n_total} x 77-token texts in total, half labeled on "
                                          f"every rank -> NCE + KD losses -> student backward -> AdamW (BASELINE configs[4])",
@@ -876,7 +938,7 @@ def main() -> None:
                              "weights": "random init (seed 42) teacher, student = teacher perturbed by 5 %; AdamW lr 3e-7",
                              "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
                              "collectives": collectives},
-                  "roofline": kd["roofline"], "split_step": kd["split_step"], "losses": kd["losses"],
+                  "roofline": kd["roofline"], "split_step": kd["split_step"], "losses": kd["losses"], "kd_forward": kd["kd_forward"],
                   "peak_memory_gb": kd["peak_memory_gb"]}
         if rank == 0:
             print(json.dumps(result), flush=True)
@@ -886,8 +948,7 @@ def main() -> None:
 
     if args.config == "c3":
         w3, enc3, video3, ids3 = run_wise_config(dims, args, shards, device, args.backend)
-        result = {**base, "metric": "video-text pairs/sec through command=evaluate, encoder=wise (4-frame 224^2, 77-tok)",
-                  "value": w3["value"], "ms_per_step": w3["ms_per_step"],
+        result = {**base, "value": w3["value"], "ms_per_step": w3["ms_per_step"],
                   "config": {"workload": f"encoder=wise (0.5 CLIP + 0.5 student, ViT-B/16, blended on the device), WebVid-val shape: "
                                          f"{n_total} clips x {args.frames} frames x 224^2 + {n_total} x 77-token texts in total "
                                          f"through TextVideoRetrievalModule in eval batches of {shards.eval_batch or n_local} clips "

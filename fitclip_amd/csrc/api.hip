@@ -181,6 +181,12 @@ struct ProfScope {
   ~ProfScope() {
     if (idx >= 0) (void)hipEventRecord(h->ev[2 * idx + 1], st);
   }
+  // attention records: which arithmetic the launch ran - `epilogue` = the fc_attention precision code of the kernel (0 fp32 MFMA,
+  // 1 bf16, 3 fp32 with x3 rows out, 4 / 5 six bf16 products, 6 three fp16 products), `tile` = 1 when a split pass over its fp32
+  // output followed (sequence lengths without a fused split attention)
+  void form(int code, int split_pass = 0) {
+    if (idx >= 0) { h->recs[idx].epilogue = code; h->recs[idx].tile = split_pass; }
+  }
 };
 
 int gemm(fc_handle* h, int epi, const void* A, const void* W, const float* bias, void* C, const float* aux, int M,
@@ -338,6 +344,7 @@ int run_blocks(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S,
     FC_TRY(gemm(h, EPI_BIAS_T, s.xn, b.in_w, b.in_b, s.big, nullptr, M, 3 * w, w, 3 * w, lab_ln_fuse() && kind == 0 && l > 0 ? 1 : 0, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
+      ps.form(kind);
       FC_TRY(launch_attention(kind, s.big, s.xn, n_seq, S, heads, causal, st));
     }
     if (l + 1 == nl && h->cfg.prune_last_block) {
@@ -406,10 +413,13 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
       if (attention_split_supported(S, 0)) {
+        ps.form(ATTN_SPLIT);
         FC_TRY(launch_attention_split(s.big, s.xn, n_seq, S, heads, st));
       } else if (attention_x3_supported(S, 0)) {
+        ps.form(KIND_X3);
         FC_TRY(launch_attention_x3(s.big, s.xn, n_seq, S, heads, st));
       } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
+        ps.form(PREC_F32, 1);
         FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
         FC_TRY(launch_split3_rows(s.d, w, s.xn, ld3, M, w, st));
       }
@@ -459,8 +469,10 @@ int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
       if (attention_split2_supported(S, 0)) {
+        ps.form(ATTN_SPLIT2);
         FC_TRY(launch_attention_split2(s.big, s.xn, n_seq, S, heads, st, h->sat_flag));
       } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
+        ps.form(PREC_F32, 1);
         FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
         FC_TRY(launch_split2_rows(s.d, w, s.xn, ld2, M, w, h->sat_flag, st));
       }

@@ -344,8 +344,9 @@ FC_API int32_t fc_bpe_decode(const fc_bpe* t, const int64_t* ids, int32_t n, cha
 typedef struct {
   int32_t kind;      /* 0 = gemm (M,N,K); 1 = attention (M = sequences, N = heads, K = tokens); 2 = add+LayerNorm (M = rows, N = width) */
   int32_t precision; /* fc_precision */
-  int32_t epilogue;
-  int32_t tile;
+  int32_t epilogue;  /* gemm: the epilogue id; attention: the arithmetic of the kernel that ran, as fc_attention's precision code (0 fp32
+                        MFMA, 1 bf16, 3 fp32 with x3 rows out, 4 / 5 six bf16 products, 6 three fp16 products) */
+  int32_t tile;      /* gemm: the tile / row cut chosen; attention: 1 when a split pass over the fp32 output followed */
   int32_t M, N, K;
   float ms;          /* elapsed between the two events; valid after the stream has been synchronised */
 } fc_prof_record;

@@ -213,6 +213,134 @@ def test_bench_launches_its_own_ranks():
                          timeout=300, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "sum_of_ranks": 1.0}
+    doc = json.loads(lines[0])
+    assert len(lines) == 1 and (doc["dry_run"], doc["n_gpus"], doc["sum_of_ranks"]) == (True, 2, 1.0)
+    assert doc["shards [rank, first clip, clips, encoder calls]"] == [[0, 0, 256, 1], [1, 256, 256, 1]]   # c2: 256 clips per rank
     one = subprocess.run([sys.executable, str(bench), "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
     assert json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+# ------------------------------------------------------------------------------------------------------------------ eight ranks
+# The 1 -> 8 GPU curve is measured by the driver with no builder in the loop: everything rank-dependent on the path - shard
+# arithmetic, the padded ragged gather, the rank gather behind the median, the packed four-tensor gather of the distillation step,
+# both `loss/val` semantics, bench.py's launcher and shard plans - has run at world size 8 here, on gloo (tensor_utils.py:48-66,
+# metrics.py:13 of the reference).
+
+def test_sharded_retrieval_on_eight_ranks_with_a_ragged_total(tmp_path):
+    n = 8192 + 3   # BASELINE configs[3]'s size plus a remainder: shards of 1025, 1025, 1025, 1024, ...
+    out = str(tmp_path / "m8.npy")
+    mp.spawn(_worker, args=(8, _free_port(), n, out), nprocs=8, join=True)
+    got = np.load(out)
+    v, t = _planted(n)
+    ref = O.retrieval_metrics(O.retrieval_scores(t, v))
+    assert got.tolist() == pytest.approx([ref["r1"], ref["r5"], ref["r10"], ref["mr"]])
+    assert D.shard_counts(n, 8) == [1025, 1025, 1025, 1024, 1024, 1024, 1024, 1024]
+
+
+def _ts8_worker(rank: int, world: int, port: int, n: int, out_path: str) -> None:
+    _ts_worker(rank, world, port, n, out_path)
+
+
+def test_teacher_student_step_end_on_eight_ranks(tmp_path):
+    """The packed all-gather of the four embedding matrices (`all_gather_many`) and the full-batch NCE / KD losses with every rank
+    holding an eighth of BASELINE configs[4]'s 512 clips."""
+    n, out = 512, str(tmp_path / "ts8")
+    mp.spawn(_ts8_worker, args=(8, _free_port(), n, out), nprocs=8, join=True)
+    sv, st = _planted(n, seed=1)
+    tv, tt = _planted(n, seed=2)
+    s, t = O.step_scores(sv, st, 0.05), O.step_scores(tv, tt, 0.05)
+    want = [float(O.nce_loss(s)), float(O.teacher_student_nce_loss(s, t) * (1 / 0.05) ** 2)]
+    for rank in range(8):
+        assert np.load(out + f".{rank}.npy").tolist() == pytest.approx(want, rel=1e-5)
+
+
+def test_loss_val_semantics_on_eight_ranks(tmp_path):
+    """Both meanings of `loss/val` at world size 8 over the exact shards of 103 clips (13 x 7 + 12): a ragged last step - one row
+    on ranks 0-6, nothing left on rank 7, which feeds an empty batch into the step's collective."""
+    sizes = tuple((6, 6, 1) if r < 7 else (6, 6, 0) for r in range(8))
+    n = sum(sum(r) for r in sizes)
+    assert [sum(r) for r in sizes] == D.shard_counts(n, 8)
+    v, t = _planted(n, seed=3)
+    ref = O.retrieval_metrics(O.retrieval_scores(t, v))
+    offs = [sum(sum(sizes[q]) for q in range(r)) for r in range(8)]
+    num = den = 0.0
+    pos = list(offs)
+    for step in range(3):   # the reference's number: step i gathers every rank's batch i, in rank order
+        rows = []
+        for r in range(8):
+            rows += list(range(pos[r], pos[r] + sizes[r][step]))
+            pos[r] += sizes[r][step]
+        num += float(O.nce_loss(O.step_scores(v[rows], t[rows], 0.015))) * len(rows)
+        den += len(rows)
+    want_gathered = num / den
+    num = den = 0.0
+    for r in range(8):      # the default's number: every local batch on its own, weighted by its size
+        p = offs[r]
+        for b in sizes[r]:
+            if b:
+                num += float(O.nce_loss(O.step_scores(v[p:p + b], t[p:p + b], 0.015))) * b
+                den += b
+            p += b
+    want_local = num / den
+    assert want_gathered > want_local + 1e-3
+    for gather, want in ((True, want_gathered), (False, want_local)):
+        out = str(tmp_path / f"lv8{int(gather)}")
+        mp.spawn(_loss_val_worker, args=(8, _free_port(), sizes, gather, out), nprocs=8, join=True)
+        for rank in range(8):
+            got = np.load(out + f".{rank}.npy")
+            assert got[0] == pytest.approx(want, rel=1e-5), (gather, rank)
+            assert got[1:].tolist() == pytest.approx([ref["r1"], ref["r5"], ref["r10"], ref["mr"]])
+
+
+@pytest.mark.parametrize("argv,want", [
+    (["--config", "c4"], {"metric": "video-text pairs/sec (16-frame 224^2, 77-tok)", "frames": 16, "scaling": "strong", "n_total": 8192,
+                          "shards": [[r, 1024 * r, 1024, 8] for r in range(8)]}),
+    (["--config", "c4", "--total-clips", "8195", "--eval-batch", "500"],
+     {"metric": "video-text pairs/sec (16-frame 224^2, 77-tok)", "frames": 16, "scaling": "strong", "n_total": 8195,
+      "shards": [[0, 0, 1025, 3], [1, 1025, 1025, 3], [2, 2050, 1025, 3]] + [[r, 3075 + 1024 * (r - 3), 1024, 3] for r in range(3, 8)]}),
+    (["--config", "c5"], {"metric": "video-text pairs/sec through the KD training step (8-frame 224^2, 77-tok)", "frames": 8,
+                          "scaling": "strong", "n_total": 512, "shards": [[r, 64 * r, 64, 1] for r in range(8)]}),
+    (["--config", "c3", "--frames", "2"], {"metric": "video-text pairs/sec through command=evaluate, encoder=wise (2-frame 224^2, 77-tok)",
+                                          "frames": 2, "scaling": "strong", "n_total": 4096, "shards": [[r, 512 * r, 512, 16] for r in range(8)]}),
+    ([], {"metric": "video-text pairs/sec (8-frame 224^2, 77-tok)", "frames": 8, "scaling": "weak", "n_total": 2048,
+          "shards": [[r, 256 * r, 256, 1] for r in range(8)]}),
+])
+def test_bench_plans_eight_ranks(argv, want):
+    """`python bench.py --gpus 8 <config> --dry-run`: eight rank processes (bench.py's own launcher, gloo), every rank derives its
+    shard with the code the GPU run uses, rank 0 prints what the N-rank line would say about the workload: the metric string
+    carries the configuration's frame count (c4 is a 16-frame workload), the shards are exact and contiguous."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    bench = Path(__file__).resolve().parent.parent / "bench.py"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, str(bench), "--gpus", "8", "--dry-run", *argv], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    doc = json.loads(lines[0])
+    assert (doc["n_gpus"], doc["sum_of_ranks"]) == (8, 28.0)
+    got = {"metric": doc["metric"], "frames": doc["frames"], "scaling": doc["scaling"], "n_total": doc["n_total"],
+           "shards": doc["shards [rank, first clip, clips, encoder calls]"]}
+    assert got == want
+
+
+def test_bench_describes_the_arithmetic_from_the_librarys_records():
+    """`fp32_split_mode.dtype` is built from the attention records of the instrumented step (fc_prof_record.epilogue = the
+    fc_attention precision code that ran, .tile = a split pass followed), not from a string constant."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_module", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    text = {"kind": 1, "epilogue": 0, "tile": 0, "K": 77}
+    fused = [{"kind": 1, "epilogue": 6, "tile": 0, "K": 197}, text, {"kind": 0, "epilogue": 10, "tile": 3, "K": 768}]
+    assert bench.attention_description(fused, 197) == "three fp16 MFMA products per fp32 product"
+    dtype = bench.SPLIT_MODES["fp32x3"][5].format(attention=bench.attention_description(fused, 197))
+    assert dtype.count("three fp16 MFMA products per fp32 product") == 2 and "six bf16" not in dtype
+    fallback = [{"kind": 1, "epilogue": 0, "tile": 1, "K": 257}, text]
+    assert bench.attention_description(fallback, 257) == "fp32-input MFMA + a split pass over its fp32 output"
+    assert bench.attention_description([text], 197) == "none recorded"
+    assert bench.metric_name("c2", 8) == "video-text pairs/sec (8-frame 224^2, 77-tok)"   # BASELINE.json's string at the default
+    assert "16-frame" in bench.metric_name("c4", 16) and "4-frame" in bench.metric_name("c3", 4)

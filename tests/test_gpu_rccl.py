@@ -51,3 +51,25 @@ def test_bench_runs_its_rccl_path_on_one_rank():
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["collectives"].startswith("nccl process group"), out["config"]
     assert 0.0 <= out["retrieval"]["r1"] <= 1.0 and out["retrieval"]["n"] == 16
+
+
+def test_bench_line_describes_the_configuration_that_ran():
+    """The claims record follows the configuration, not string constants: the metric carries the frame count of the run, the
+    three-product leg names the arithmetic its kernels used (from the library's own records of the instrumented step: the fused
+    three-fp16-product attention at ViT-B/16's 197 tokens), and `--config c5` has the forward-only number of BASELINE configs[4]."""
+    run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--clips", "16", "--frames", "2",
+                          "--no-cpu-baseline", "--no-bf16-mode", "--no-train-leg", "--truth-clips", "0"], capture_output=True, text=True,
+                         timeout=900, cwd=str(ROOT))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    out = json.loads([line for line in run.stdout.splitlines() if line.startswith("{")][-1])
+    assert out["metric"] == "video-text pairs/sec (2-frame 224^2, 77-tok)" and "x 2 frames" in out["config"]["workload"]
+    split = out["fp32_split_mode"]
+    assert split["precision"] == "fp32x3" and split["dtype"].count("three fp16 MFMA products per fp32 product") == 2, split["dtype"]
+    assert "six bf16" not in split["dtype"]
+    c5 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "c5", "--steps", "1", "--warmup", "1", "--total-clips", "8",
+                         "--frames", "2"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert c5.returncode == 0, (c5.stdout[-2000:], c5.stderr[-4000:])
+    doc = json.loads([line for line in c5.stdout.splitlines() if line.startswith("{")][-1])
+    assert doc["metric"] == "video-text pairs/sec through the KD training step (2-frame 224^2, 77-tok)" and doc["config"]["frames"] == 2
+    fwd = doc["kd_forward"]
+    assert fwd["value"] > doc["value"] > 0 and len(fwd["losses"]) == 2 and all(l == l for l in fwd["losses"])
