@@ -754,6 +754,8 @@ def run_wise_config(dims, args, shards, device, backend):
             for s in range(0, n, batch):
                 module.validation_step_end(module.validation_step(
                     {"video": video[s:s + batch], "text": {"input_ids": ids[s:s + batch]}, "video_id": list(range(s, min(n, s + batch)))}))
+                if args.sync_batches:
+                    torch.cuda.synchronize()   # (profiling aid: bounds how far the host runs ahead of the GPU queue)
             return module.validation_epoch_end()
 
     for _ in range(max(1, args.warmup)):
@@ -838,6 +840,10 @@ def main() -> None:
                     help="c5: clips whose activations are kept (default: as many as fit, from the free device memory)")
     ap.add_argument("--headline-only", action="store_true",
                     help="c3: skip the eval-batch-256 and hipGraph legs (profiling runs: one call shape in the kernel trace)")
+    ap.add_argument("--sync-batches", action="store_true",
+                    help="c3: a host synchronisation after every eval batch (never for a timed number: the reference's loop has none). "
+                         "Under `rocprofv3 --pmc` it bounds the queue depth the profiler's packet interception has to carry "
+                         "(tools/pmc_scaling_probe.py)")
     ap.add_argument("--all-legs", action="store_true",
                     help="with more than one rank, also run the secondary legs (bf16_mode, fp32_split_mode); default: headline only")
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"],

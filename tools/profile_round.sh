@@ -63,11 +63,12 @@ fi
 pmc_extra=""
 if [ "$prec" = c3 ]; then
   common="--config c3 --no-cpu-baseline --headline-only"
-  # (a full epoch - 128 batches x ~330 launches = 42 k dispatches - cannot be profiled under --pmc: from some thousands of
-  # intercepted dispatches on (between 2.6 k and 10.5 k) the queue aborts with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT, raised
-  # by the runtime on a packet the profiler's interception rewrote; the same run WITHOUT --pmc completes - measured in
-  # tools/pmc_scaling_probe.py, profiles/r05_pmc_scaling_probe.log.  8 batches of 32 clips run the same kernels on the same shapes)
-  pmc_extra="--total-clips 256"
+  # (the evaluate loop enqueues a whole epoch without a host synchronisation; under --pmc a 1024-clip run of it aborted the queue
+  # with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT in round 5, and the SAME run with the queue drained after every eval batch
+  # (--sync-batches) passes - 18.7 k dispatches profiled: it is the depth of the host's run-ahead over the intercepted queue that
+  # breaks, not a kernel and not the dispatch count (tools/pmc_scaling_probe.py, profiles/r06_pmc_scaling_probe.log).  The PMC
+  # passes therefore run 8 batches of 32 clips - the same kernels on the same shapes - and synchronise per batch)
+  pmc_extra="--total-clips 256 --sync-batches"
 elif [ "$prec" = fp32x3 ]; then
   common="--precision fp32 --no-bf16-mode --no-cpu-baseline --no-train-leg"
 elif [ "$prec" = fp32x6 ]; then
