@@ -221,7 +221,7 @@ class CLIP(nn.Module):
         if self.chunk_frames > 0:
             return self.chunk_frames
         if self.precision in _SPLIT_GEMM:
-            return 768 if _SPLIT_GEMM[self.precision] == 1 else 1024
+            return 768 if _SPLIT_GEMM[self.precision] == 1 else 2048
         return 2048  # order of the library's pass size (ViT-B/16; csrc/api.hip planned_chunk)
 
     def _encode_image_lanes(self, rt: "_Runtime", image: torch.Tensor, out: torch.Tensor, lanes: int) -> None:

@@ -500,7 +500,9 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
   const fc_config& c = h->cfg;
   if (tower == 1) return c.chunk_texts > 0 ? c.chunk_texts : 1024;
   if (c.chunk_frames > 0) return c.chunk_frames;
-  return h->split2() ? 1024 : h->split() ? 768 : 2048;   // (split2: measured in DESIGN.md section 8)
+  // split2 (three fp16 products): round 5's 32x32x16 kernel ran 768 / 1024 / 2048 alike; on the 16x16x32 kernel of round 6 the bench
+  // step takes 201.3 / 199.6 / 199.5 / 198.7 ms in passes of 512 / 768 / 1024 / 2048 frames (tools/x3_e2e.py, profiles/r06_x3_e2e.log)
+  return h->split2() ? 2048 : h->split() ? 768 : 2048;
 }
 
 size_t per_item_bytes(const fc_handle* h, int tower) {

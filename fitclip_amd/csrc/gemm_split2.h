@@ -56,7 +56,9 @@ constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
 // epilogue (MFMA + LDS reads only); 4 = the real kernel with s_memtime stamps around the hand-over wait, the hand-over barrier, the
 // K loop and the epilogue, summed per wave into g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).  RW: residual rows requested RW patches (16 rows x 32 columns) ahead (EPI_RESID3_F32).
 // PF: activation fragments requested PF row tiles ahead (2: three register sets, 256-row tiles only)
-template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1>
+// PRIO (lab): 1 = waves 4..7 (the later-dispatched partner on every SIMD) at s_setprio 2 for the whole kernel; 2 = the two halves
+// take the higher priority in alternate K-steps; 3 = waves 0..3 at s_setprio 2
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1, int PRIO = 0>
 __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   constexpr int BM = BMT, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 (64) x 64 per wave
@@ -181,6 +183,8 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
     for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const f16x8*>(smem + a_base + foff[p] + (stage * STG_A + i * 16 * ROWB));
   };
 
+  if constexpr (PRIO == 1) { if (wave >= 4) __builtin_amdgcn_s_setprio(2); }
+  if constexpr (PRIO == 3) { if (wave < 4) __builtin_amdgcn_s_setprio(2); }
   int m0, n0;
   tile_sources(t, m0, n0);
   bias_load(0, n0);
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   read_a(0, 0, af[0]);
   int it = 0;                 // tile iteration (bias buffer = it & 1)
   bool prev_counted = false;  // the previous tile issued exactly NST stores behind its prefetches
-  unsigned long long st_data = 0, st_bar = 0, st_k = 0, st_epi = 0, st_mark = 0, st_tiles = 0;   // (ABL == 4)
+  unsigned long long st_data = 0, st_bar = 0, st_k = 0, st_epi = 0, st_mark = 0, st_tiles = 0, st_g4 = 0, st_half = 0, st_g0 = 0, st_first = 0;   // (ABL == 4)
   auto stamp = [] { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
 
   for (;;) {
@@ -222,9 +226,17 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
       constexpr int par = decltype(PAR)::value;
       constexpr bool first = decltype(FIRST)::value;
       const bool last = kt == nk - 1;
+      if constexpr (PRIO == 2) {
+        if ((wave >= 4) == (par == 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+      }
       static_for<NG>([&](auto U) {
         constexpr int u = decltype(U)::value;
         constexpr bool tail = u + 1 == NG;
+        if constexpr (ABL == 4 && u == 0 && !first) st_g0 = stamp();
+        if constexpr (ABL == 4 && u == NG / 2 && !first) {
+          st_g4 = stamp();
+          st_first += st_g4 - st_g0;       // groups 0 .. NG / 2 - 1 of this wave
+        }
         if constexpr (!tail) {
           // the planes of the row tile PF groups ahead are requested before this group's MFMAs (PF = 2: the first group of a
           // K-step requests two row tiles - the hand-over in front of the last group has only published row tile 0)
@@ -240,6 +252,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             unsigned long long s0 = 0, s1 = 0;
             if constexpr (ABL == 4) s0 = stamp();
+            if constexpr (ABL == 4 && !first) st_half += s0 - st_g4;   // groups NG / 2 .. NG - 2 of this wave
             if constexpr (ABL < 5) {
               if (kt == 0 && prev_counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
             }
@@ -471,7 +484,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   if constexpr (ABL == 4) {
     if (lane == 0 && g.aux) {
       unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.aux)) + ((size_t)blockIdx.x * NW + wave) * 8;
-      d[0] = st_data; d[1] = st_bar; d[2] = st_k; d[3] = st_epi; d[4] = st_tiles; d[5] = (unsigned long long)nk;
+      d[0] = st_data; d[1] = st_bar; d[2] = st_k; d[3] = st_epi; d[4] = st_tiles; d[5] = (unsigned long long)nk; d[6] = st_first; d[7] = st_half;
     }
   }
   wait_vmcnt<0>();   // (the unread pieces behind the last K-step: no LDS-DMA may be in flight when the workgroup's LDS is released)

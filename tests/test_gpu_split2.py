@@ -344,7 +344,7 @@ def test_evaluate_goldens_in_three_product_mode(golden_dir, vitb16_state_dict):
 def test_big_pass_and_ragged_tail_agree_with_the_fp32_path(vitb16_state_dict):
     """1100 frames: one 1024-frame pass + a 76-frame pass, against the fp32-MFMA path on the same frames, and a batch computed
     in pieces equals the batch computed at once (rows are independent)."""
-    split = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV)
+    split = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV, chunk_frames=1024)   # (the default pass holds 2048 frames)
     plain = build_clip(vitb16_state_dict, precision="fp32", device=DEV)
     g = torch.Generator(device=DEV).manual_seed(3)
     base = torch.randn(25, 3, 224, 224, device=DEV, generator=g).clamp_(-2.5, 2.5)
@@ -355,6 +355,8 @@ def test_big_pass_and_ragged_tail_agree_with_the_fp32_path(vitb16_state_dict):
     assert diff < 1e-5, diff
     assert torch.equal(got[:25], got[25:50]) and torch.equal(got[:25], got[1075:1100])  # same frame, same bits, any pass
     assert torch.equal(split.encode_image(frames[:7].contiguous()), got[:7])
+    one_pass = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV)
+    assert torch.equal(one_pass.encode_image(frames), got)                               # ... and any pass size
 
 
 def test_mode_is_as_close_to_float64_as_fp32_arithmetic_itself(vitb16_state_dict):

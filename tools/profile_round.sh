@@ -44,13 +44,13 @@ elif [ "$prec" = bf16 ]; then
   spec_fc="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi1E|1000|1e9|$rows|3072|768|bias_quickgelu"
   spec_proj="gemm_pipelined_kernelIDF16bLi256ELi256ELi2ELi4ELi2E|1000|1e9|$rows|768|3072|bias_residual"
 elif [ "$prec" = fp32x3 ]; then
-  # fp32x3 = the split-fp32 leg of the fp32 bench run (round 5): the 2048 frames of a step run as 1024 + 1024; two-plane fp16
-  # operands, three fp16 products per fp32 product (the K below is 3 K).  c_fc (QuickGELU + x2 rows) has its own instantiation
-  # (epilogue 10; 2.4 ms at 1024 frames); c_proj shares epilogue 8 with out_proj and is the only one of the two above 1.5 ms
-  # (at 1024 frames: c_proj 2.3, out_proj 0.7)
-  steps=3; chunk=1024; rows=$((chunk * 197))
-  spec_fc="gemm_split2_kernel<10,|2000|1e9|$rows|3072|2304|bias_quickgelu_x2_out"
-  spec_proj="gemm_split2_kernel<8,|1500|1e9|$rows|768|9216|bias_residual_f32_out"
+  # fp32x3 = the split-fp32 leg of the fp32 bench run: the 2048 frames of a step run as ONE pass (round 6; 1024 + 1024 in round 5);
+  # two-plane fp16 operands, three fp16 products per fp32 product (the K below is 3 K).  c_fc (QuickGELU + x2 rows) has its own
+  # instantiation (epilogue 10; 4.45 ms at 2048 frames); c_proj shares epilogue 8 with out_proj and is the only one of the two
+  # above 3 ms (at 2048 frames: c_proj 4.0, out_proj 1.2)
+  steps=3; chunk=2048; rows=$((chunk * 197))
+  spec_fc="gemm_split2_kernel<10,|3500|1e9|$rows|3072|2304|bias_quickgelu_x2_out"
+  spec_proj="gemm_split2_kernel<8,|3000|1e9|$rows|768|9216|bias_residual_f32_out"
 else
   # fp32x6 = the split-fp32 leg of the fp32 bench run (the 2048 frames of a step run as 768 + 768 + 512; three-plane operands,
   # six bf16 products per fp32 product: the K below is 6 K): c_fc with the QuickGELU + x3 epilogue has its own instantiation

@@ -82,9 +82,9 @@ void launch_m32(const GemmArgs& a, hipStream_t st) {   // the 32x32x16 kernel
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), kSplit2Lds, st, a);
 }
-template <int EPI, int ABL, int SPREAD = 0, int RW = 4, int PF = 1>
+template <int EPI, int ABL, int SPREAD = 0, int RW = 4, int PF = 1, int PRIO = 0>
 void launch_k32(const GemmArgs& a, hipStream_t st) {   // the 16x16x32 kernel
-  auto kern = gemm_split2_kernel<EPI, ABL, SPREAD, RW, 0, 256, PF>;
+  auto kern = gemm_split2_kernel<EPI, ABL, SPREAD, RW, 0, 256, PF, PRIO>;
   static bool configured = false;
   if (!configured) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSplit2Lds));
@@ -142,21 +142,21 @@ int main(int argc, char** argv) {
     const int ns = sh.epi == 1 ? 4 : 0;
     if (sh.epi == 1) {
       vs = {{"m32 shipped", launch_m32<EPI_GELU_X2, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_GELU_X2, 0, 3>, ns},
-            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
+            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_GELU_X2, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_GELU_X2, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_GELU_X2, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_GELU_X2, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_GELU_X2, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_GELU_X2, 6, 3>, ns},
             {"k32 ABL4 stamps", launch_k32<EPI_GELU_X2, 4, 5>, ns}};
     } else if (sh.epi == 2) {
       vs = {{"m32 shipped", launch_m32<EPI_RESID3_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_RESID3_F32, 0, 3>, ns},
-            {"k32 spread5", launch_k32<EPI_RESID3_F32, 0, 5>, ns}, {"k32 spread5 pf2", launch_k32<EPI_RESID3_F32, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_RESID3_F32, 4, 5, 4, 2>, ns},
+            {"k32 spread5", launch_k32<EPI_RESID3_F32, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_RESID3_F32, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_RESID3_F32, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_RESID3_F32, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_RESID3_F32, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_RESID3_F32, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_RESID3_F32, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_RESID3_F32, 4, 5, 4, 2>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_RESID3_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_RESID3_F32, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_RESID3_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_RESID3_F32, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_RESID3_F32, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_RESID3_F32, 6, 3>, ns},
             {"k32 ABL4 stamps", launch_k32<EPI_RESID3_F32, 4, 5>, ns}};
     } else {
       vs = {{"m32 shipped", launch_m32<EPI_BIAS_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_BIAS_F32, 0, 3>, ns},
-            {"k32 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, ns}, {"k32 spread5 pf2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 2>, ns},
+            {"k32 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_BIAS_F32, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 2>, ns},
             {"k32 ABL4 stamps pf2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 2>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_BIAS_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_BIAS_F32, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_BIAS_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_BIAS_F32, 3, 3>, ns},
@@ -241,12 +241,13 @@ int main(int argc, char** argv) {
       HIP_OK(hipMemcpyAsync(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost, st));
       HIP_OK(hipStreamSynchronize(st));
       double sd = 0, sb = 0, sk = 0, se = 0, tiles = 0, nkk = 0; int n = 0;
-      double wd[8] = {0}, wb[8] = {0};
+      double wd[8] = {0}, wb[8] = {0}, wf[8] = {0}, wh[8] = {0};
       for (int w = 0; w < 256 * 8; ++w) {
         const unsigned long long* d = &h[(size_t)w * 8];
         if (!d[4]) continue;
         sd += (double)d[0]; sb += (double)d[1]; sk += (double)d[2]; se += (double)d[3]; tiles += (double)d[4]; nkk = (double)d[5]; ++n;
         wd[w & 7] += (double)d[0] / d[4]; wb[w & 7] += (double)d[1] / d[4];
+        wf[w & 7] += (double)d[6] / d[4] / (d[5] - 1); wh[w & 7] += (double)d[7] / d[4] / (d[5] - 1);
       }
       printf("%s stamps (%d waves): per tile: K loop %.0f cycles, epilogue %.0f; inside the K loop per K-step: wait for the next K-step's data %.0f, at the hand-over barrier %.0f (of %.0f per K-step)\n",
              sh.name, n, sk / tiles, se / tiles, sd / tiles / (nkk - 1), sb / tiles / (nkk - 1), sk / tiles / nkk);
@@ -254,6 +255,10 @@ int main(int argc, char** argv) {
       for (int w = 0; w < 8; ++w) printf(" %.0f", wd[w] / (n / 8));
       printf("; barrier wait per tile");
       for (int w = 0; w < 8; ++w) printf(" %.0f", wb[w] / (n / 8));
+      printf("\n%s stamps by wave, per K-step: groups 0-3 (48 MFMAs + the LDS-DMA pieces)", sh.name);
+      for (int w = 0; w < 8; ++w) printf(" %.0f", wf[w] / (n / 8));
+      printf("; groups 4-6 (36 MFMAs)");
+      for (int w = 0; w < 8; ++w) printf(" %.0f", wh[w] / (n / 8));
       printf("\n");
     }
     printf("%s: saturation flag after the runs %d\n", sh.name, hflag);
