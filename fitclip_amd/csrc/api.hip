@@ -143,14 +143,17 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
         l.push_back({b + n, h->split2() ? PACK_SPLIT2 : PACK_SPLIT3});
     }
   }
+  if (h->x2_patch()) l.push_back({"visual.conv1.weight", PACK_SPLIT2});   // [width, 3, p, p] = [width, 3 p^2] rows
   l.push_back({"visual.proj", PACK_TRANSPOSE});
   l.push_back({"text_projection", PACK_TRANSPOSE});
   return l;
 }
+// a weight as a matrix [rows, K]: the leading dimension against everything behind it (conv1.weight [width, 3, p, p])
+inline long weight_cols(const std::vector<int64_t>& shape) { return shape.empty() || !shape[0] ? 0 : (long)(numel(shape) / (size_t)shape[0]); }
 size_t packed_item_bytes(const fc_handle* h, const PackItem& e) {
   const auto& shape = h->slots.at(e.name).shape;
   if (e.mode == PACK_SPLIT3) return align_up((size_t)shape[0] * (size_t)x3_row_elems(shape[1]) * 2);
-  if (e.mode == PACK_SPLIT2) return align_up((size_t)shape[0] * (size_t)x2_row_elems(shape[1]) * 2) + 256;  // + the scale pair
+  if (e.mode == PACK_SPLIT2) return align_up((size_t)shape[0] * (size_t)x2_row_elems(weight_cols(shape)) * 2) + 256;  // + the scale pair
   const size_t n = e.mode == PACK_PAD_ROWS ? (size_t)shape[0] * h->patch_kp() : numel(shape);
   return align_up(n * h->esz);
 }
@@ -439,10 +442,10 @@ int run_blocks_x3(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
 // products per fp32 product (gemm_split2.h).  Producers: LayerNorm (KIND_X2), the split attention (x2 rows out), c_fc's QuickGELU
 // epilogue (EPI_GELU_X2).  Every writer of x2 rows raises h->sat_flag when a value exceeds fp16's range.
 int gemm_x2(fc_handle* h, int epi, const void* A2, const void* W2, const float* scale2, const float* bias, void* C, int M, int N,
-            int K, int ldc, hipStream_t st) {
+            int K, int ldc, hipStream_t st, const float* aux = nullptr, int P = 0) {
   GemmArgs a{};
-  a.A = A2; a.W = W2; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f; a.wscale = scale2; a.sat_flag = h->sat_flag;
-  a.M = M; a.N = N; a.K = K; a.lda = (int)x2_row_elems(K); a.ldw = a.lda; a.ldc = ldc; a.P = 0;
+  a.A = A2; a.W = W2; a.bias = bias; a.C = C; a.aux = aux; a.alpha = 1.f; a.wscale = scale2; a.sat_flag = h->sat_flag;
+  a.M = M; a.N = N; a.K = K; a.lda = (int)x2_row_elems(K); a.ldw = a.lda; a.ldc = ldc; a.P = P;
   GemmArgs rec = a;  // the profiling record counts the fp16 work: three products per fp32 product (precision code 2 = fp16 pipe)
   rec.K = 3 * K;
   ProfScope ps(h, st, 2, epi, 3, rec);
@@ -588,6 +591,7 @@ size_t fc_packed_bytes(const fc_handle* h) {
   size_t total = 0;
   for (auto& e : packed_list(h)) total += packed_item_bytes(h, e);
   if (h->split2()) total += 256;  // the range flag of the x2 writers
+  if (h->x2_patch()) total += align_up((size_t)h->cfg.vision_width * 4);  // the zero bias of the patch-embedding GEMM (behind the flag)
   return total;
 }
 
@@ -604,7 +608,14 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
   // are split - a tensor with an infinite or NaN weight raises it
   int* flag = nullptr;
   if (h->split2()) {
-    flag = reinterpret_cast<int*>(static_cast<char*>(arena) + (fc_packed_bytes(h) - 256));
+    const size_t tail = 256 + (h->x2_patch() ? align_up((size_t)h->cfg.vision_width * 4) : 0);   // [flag | zero bias]
+    flag = reinterpret_cast<int*>(static_cast<char*>(arena) + (fc_packed_bytes(h) - tail));
+    h->zero_bias = nullptr;
+    if (h->x2_patch()) {
+      float* zb = reinterpret_cast<float*>(reinterpret_cast<char*>(flag) + 256);
+      if (hipMemsetAsync(zb, 0, (size_t)h->cfg.vision_width * 4, stream) != hipSuccess) return fail(FC_ELAUNCH, "fc_pack_weights: memset");
+      h->zero_bias = zb;
+    }
     if (!h->sat_host && hipHostMalloc(reinterpret_cast<void**>(&h->sat_host), 64, hipHostMallocDefault) != hipSuccess)
       return fail(FC_ENOMEM, "fc_pack_weights: cannot allocate the pinned mirror of the range flag");
     *h->sat_host = 0;
@@ -626,8 +637,8 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
     } else if (e.mode == PACK_SPLIT2) {  // [the x2 image | 256 bytes: the {s, 1 / s} pair]
       const size_t img = packed_item_bytes(h, e) - 256;
       float* sc = reinterpret_cast<float*>(static_cast<char*>(dst) + img);
-      FC_TRY(launch_split2_weight(slot.ptr, (long)slot.shape[1], dst, x2_row_elems(slot.shape[1]), (long)slot.shape[0],
-                                  (int)slot.shape[1], sc, flag, stream));
+      const long wk = weight_cols(slot.shape);
+      FC_TRY(launch_split2_weight(slot.ptr, wk, dst, x2_row_elems(wk), (long)slot.shape[0], (int)wk, sc, flag, stream));
       packed[e.name + "#x2"] = dst;
       packed[e.name + "#s2"] = sc;
       off += packed_item_bytes(h, e);
@@ -683,6 +694,13 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
     h->sat_flag = nullptr;
   }
   h->conv_w = gw("visual.conv1.weight");
+  h->conv_w2 = nullptr;
+  h->conv_s2 = nullptr;
+  if (h->x2_patch()) {
+    h->conv_w2 = packed.at("visual.conv1.weight#x2");
+    h->conv_s2 = static_cast<const float*>(packed.at("visual.conv1.weight#s2"));
+    h->conv_w = h->w("visual.conv1.weight");   // (the fp32 tensor: passes too small for the plane GEMM take the fp32 path)
+  }
   h->vproj_t = gw("visual.proj");
   h->tproj_t = gw("text_projection");
   h->packed = true;
@@ -724,7 +742,14 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     const Scratch s = carve(static_cast<char*>(ws), cn, T, vw, h->esz, Kp, split);
     const float* f = frames + (size_t)off * 3 * R * R;
     const int p = c.vision_patch_size;
-    if (kind == PREC_F32 && Kp == h->patch_k() && p % 4 == 0 && R % 4 == 0) {
+    if (split == 2 && h->conv_w2 && x2_pass_ok(cn * T, vw) && cn * P < (1 << 23)) {
+      // three-product mode: the patch embedding is a plane GEMM too - the frames become x2 rows of the im2col matrix in one pass
+      // (in the MLP-hidden buffer, free until the first block), the GEMM's epilogue adds the positional embedding and leaves the
+      // class rows out.  3.78 -> 1.7 ms per 2048 frames (fp32-MFMA GEMM with the patch gather in its loader: 0.87 of ITS peak)
+      FC_TRY(launch_im2col_x2(f, s.big, x2_row_elems(Kp), cn, R, p, h->sat_flag, st));
+      FC_TRY(gemm_x2(h, EPI_PATCH_F32, s.big, h->conv_w2, h->conv_s2, h->zero_bias, s.x, cn * P, vw, Kp, vw, st,
+                     h->w("visual.positional_embedding"), P));
+    } else if (kind == PREC_F32 && Kp == h->patch_k() && p % 4 == 0 && R % 4 == 0) {
       // fp32 mode: the GEMM's LDS-DMA loader gathers the 16 x 16 x 3 patches straight from the NCHW frames (16-byte
       // pieces of 4 pixels): the frames are read once, no im2col matrix is written to / re-read from HBM
       GemmArgs a{};

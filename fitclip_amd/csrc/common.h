@@ -167,6 +167,9 @@ int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long
 // infinite or NaN weight (it cannot be split; scale 1, the planes carry the infinities / NaNs)
 int launch_split2_weight(const float* w, long ld_in, void* out, long ld_out, long rows, int K, float* scale2, int* sat_flag,
                          hipStream_t stream);
+// x2 rows [n g^2, 2 * 3 p^2 fp16 positions] of the im2col matrix of frames f32 [n, 3, res, res] (the patch embedding's operand in the
+// three-product mode; patch % 8 == 0); launch_gemm_split2(EPI_PATCH_F32) adds the positional embedding and skips the class rows
+int launch_im2col_x2(const float* frames, void* out, long ld_out, int n, int res, int patch, int* sat_flag, hipStream_t stream);
 // raises *sat_flag when LayerNorm outputs under (gamma, beta) could leave fp16's range: sqrt(D) max|gamma| + max|beta| > 65504
 int launch_x2_ln_bound(const float* gamma, const float* beta, int D, int* sat_flag, hipStream_t stream);
 // the row cut of the fp32 pipelined kernel for an [M, N] output over K columns on the current device: 256-row panels of the head (whole tile

@@ -79,9 +79,11 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   constexpr int OFF_BIAS = OFF_STG + NW * 2048;    // 2 x 1 KiB
   constexpr bool kOutX2 = EPI == EPI_GELU_X2;
   constexpr bool kResid = EPI == EPI_RESID3_F32;   // C += acc + bias (fp32, in place)
+  constexpr bool kPatch = EPI == EPI_PATCH_F32;    // C[m + m / P + 1] = acc + pos[m % P + 1] (patch embedding into the token stream)
+  constexpr bool kAdd = kResid || kPatch;          // the epilogue adds rows it fetches RW patches ahead
   constexpr int NP = FM * (FN / 2);                // patches (16 rows x 32 columns) per wave and tile: 16 (8)
   constexpr int NST = NP * 2;                      // store instructions per wave and interior tile: 32 (16)
-  static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X2 || EPI == EPI_RESID3_F32, "epilogue");
+  static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X2 || EPI == EPI_RESID3_F32 || EPI == EPI_PATCH_F32, "epilogue");
   static_assert(LPW + NST < 64, "the counted wait behind the epilogue stores must fit the 6-bit vmcnt");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -370,24 +372,42 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
         auto patch_fence = [] { asm volatile("" ::: "memory"); };
         // (the interior body is one basic block of 16 patches: without a scheduling fence per patch hipcc computes several patches
         // ahead and spills ~90 registers)
-        auto patch_end = [&] { patch_fence(); __builtin_amdgcn_sched_barrier(0); };
+        auto patch_end = [&] { patch_fence(); if constexpr (!kOutX2) __builtin_amdgcn_sched_barrier(0); };
         const int rd_off[2] = {rrow * 128 + ((rch ^ rrow) << 4), (8 + rrow) * 128 + ((rch ^ rrow ^ 1) << 4)};
         if constexpr (!kOutX2) {
           // EPI_RESID3_F32: every lane adds the 16 bytes of C it is about to overwrite (the residual stream, updated in place);
-          // they are requested RW patches ahead, whole lines per instruction and non-temporal, like the stores
+          // they are requested RW patches ahead, whole lines per instruction and non-temporal, like the stores.
+          // EPI_PATCH_F32 (the patch embedding: row m = (image, patch) of the im2col matrix goes to token row m + m / P + 1, behind
+          // its image's class token): the same machinery fetches the positional-embedding row (m % P) + 1 of g.aux [P + 1, N]
+          // (L2-resident) instead.  m / P through the float reciprocal, exact for m < 2^23 after one correction step.
           constexpr int RWIN = RW;
-          f32x4 xres[kResid ? RWIN : 1][2];
+          f32x4 xres[kAdd ? RWIN : 1][2];
+          const float inv_p = kPatch ? 1.f / (float)g.P : 0.f;
+          auto token_row = [&](int mo, int& rem) {   // (image index, patch index) of im2col row mo
+            int q = (int)((float)mo * inv_p);
+            rem = mo - q * g.P;
+            if (rem < 0) { rem += g.P; --q; }
+            if (rem >= g.P) { rem -= g.P; ++q; }
+            return q;
+          };
           auto resid_load = [&](int pt, f32x4 (&dst)[2]) {
             const int i = pt / (FN / 2), jp = pt % (FN / 2);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
               const int mo = cm0 + wm * TM + i * 16 + s * 8 + rrow, no = cn0 + wn * TN + jp * 32 + rch * 4;
               dst[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (inter || (mo < g.M && no < g.N))
-                dst[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (size_t)mo * g.ldc + no));
+              if (inter || (mo < g.M && no < g.N)) {
+                if constexpr (kPatch) {
+                  int rem;
+                  token_row(mo, rem);
+                  dst[s] = *reinterpret_cast<const f32x4*>(g.aux + (size_t)(rem + 1) * g.N + no);
+                } else {
+                  dst[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.C) + (size_t)mo * g.ldc + no));
+                }
+              }
             }
           };
-          if constexpr (kResid) {
+          if constexpr (kAdd) {
 #pragma unroll
             for (int pt = 0; pt < RWIN && pt < NP; ++pt) resid_load(pt, xres[pt]);
           }
@@ -404,14 +424,19 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
 #pragma unroll
               for (int s = 0; s < 2; ++s) {
                 f32x4 val = *reinterpret_cast<const f32x4*>(stg + rd_off[s]);
-                if constexpr (kResid) val = xres[pt % RWIN][s] + val;
+                if constexpr (kAdd) val = xres[pt % RWIN][s] + val;
                 const int mo = cm0 + wm * TM + i * 16 + s * 8 + rrow, no = cn0 + wn * TN + jp * 32 + rch * 4;
                 if (inter || (mo < g.M && no < g.N)) {
-                  f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)mo * g.ldc + no);
+                  size_t out_row = (size_t)mo;
+                  if constexpr (kPatch) {
+                    int rem;
+                    out_row = (size_t)mo + (size_t)token_row(mo, rem) + 1;
+                  }
+                  f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + out_row * g.ldc + no);
                   __builtin_nontemporal_store(val, dst);
                 }
               }
-              if constexpr (kResid) {
+              if constexpr (kAdd) {
                 if (pt + RWIN < NP) resid_load(pt + RWIN, xres[pt % RWIN]);
               }
               patch_end();

@@ -89,6 +89,37 @@ __global__ void __launch_bounds__(256) split2_rows_kernel(const float* __restric
   if (sat_flag && amax > 0x477fe000u) atomicOr(sat_flag, 1);   // 0x477fe000 = 65504.f; infinities and NaNs lie above
 }
 
+// The patch-embedding operand of the three-product mode: frames f32 NCHW [n, 3, R, R] -> x2 rows of the im2col matrix [n g^2, 2 * 3 p^2
+// fp16 positions] (row = (image, gy, gx), column k = (channel, py, px), as `im2col` lays it out), thread per (row, 8 columns): two
+// 16-byte loads of a patch row's pixels, 16 bytes to either plane.  p % 8 == 0 (a piece never crosses a patch row), R % 4 == 0.
+__global__ void __launch_bounds__(256) im2col_x2_kernel(const float* __restrict__ frames, char* __restrict__ out, long ld_out_bytes, long rows,
+                                                        int R, int p, int* sat_flag) {
+  const int g = R / p, pp = p * p, per_row = 3 * pp / 8;
+  const long total = rows * per_row;
+  unsigned amax = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / per_row;
+    const int piece = (int)(i - row * per_row), group = piece >> 2, quarter = piece & 3;
+    const int k = piece * 8, c = k / pp, rem = k - c * pp, py = rem / p, px = rem - py * p;
+    const int gx = (int)(row % g), gy = (int)((row / g) % g);
+    const long img = row / ((long)g * g);
+    const float* src = frames + ((img * 3 + c) * R + gy * p + py) * (long)R + gx * p + px;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+    f16x4 a1, a2, b1, b2;
+    split2(lo, a1, a2);
+    split2(hi, b1, b2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = max(amax, max(__float_as_uint(lo[e]) & 0x7fffffffu, __float_as_uint(hi[e]) & 0x7fffffffu));
+    char* dst = out + row * ld_out_bytes + (long)group * X2_GROUP_BYTES + quarter * 16;
+    f16x8 v1, v2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v1[e] = a1[e]; v1[4 + e] = b1[e]; v2[e] = a2[e]; v2[4 + e] = b2[e]; }
+    *reinterpret_cast<f16x8*>(dst) = v1;
+    *reinterpret_cast<f16x8*>(dst + 64) = v2;
+  }
+  if (sat_flag && amax > 0x477fe000u) atomicOr(sat_flag, 1);
+}
+
 // max |w| over the tensor as the bits of a non-negative float (integer order = float order; a NaN anywhere in the tensor sorts
 // above infinity and survives the reduction - fmaxf would drop it)
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ w, long ld_in, long rows, int K, unsigned* out) {
@@ -176,6 +207,11 @@ int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int 
     case EPI_RESID3_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);
       return launch_x2_variant<EPI_RESID3_F32>(b, stream, force_cut);
+    case EPI_PATCH_F32:   // the patch embedding: C[m + m / P + 1] = acc + bias + aux[(m % P) + 1]  (aux = positional embedding [P + 1, N])
+      if (a.ldc % 4 || a.ldc < a.N || !a.aux || a.P <= 0 || ((uintptr_t)a.aux & 15) || a.N % 4)
+        return fail(FC_EINVAL, "gemm_split2: the patch epilogue needs the positional embedding, P > 0 and ldc=%d >= N", a.ldc);
+      if (a.M >= (1 << 23)) return fail(FC_EINVAL, "gemm_split2: the patch epilogue indexes at most 2^23 - 1 patch rows per launch (M=%d)", a.M);
+      return launch_x2_variant<EPI_PATCH_F32>(b, stream, force_cut);
     case EPI_GELU_X2:
       if (a.ldc % 64 || a.ldc < x2_row_elems(a.N) || ((uintptr_t)a.C & 127))
         return fail(FC_EINVAL, "gemm_split2: the x2 output needs 128-byte aligned rows of >= 2 N fp16 (ldc=%d)", a.ldc);
@@ -198,6 +234,19 @@ int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long
   hipLaunchKernelGGL(split2_rows_kernel, dim3(blocks), dim3(256), 0, stream, in, ld_in, static_cast<char*>(out), ld_out * 2, rows, K,
                      (const float*)nullptr, sat_flag);
   FC_CHECK_LAUNCH("split2_rows");
+  return FC_OK;
+}
+
+int launch_im2col_x2(const float* frames, void* out, long ld_out, int n, int res, int patch, int* sat_flag, hipStream_t stream) {
+  if (n <= 0) return FC_OK;
+  const int K = 3 * patch * patch;
+  if (patch <= 0 || patch % 8 || res % patch || res % 4 || K % X2_GROUP || ld_out % 64 || ld_out < x2_row_elems(K) ||
+      ((uintptr_t)frames & 15) || ((uintptr_t)out & 127))
+    return fail(FC_EINVAL, "im2col_x2: resolution %d / patch %d (a multiple of 8), alignment or row stride", res, patch);
+  const long rows = (long)n * (res / patch) * (res / patch), total = rows * (K / 8);
+  hipLaunchKernelGGL(im2col_x2_kernel, dim3((int)std::min<long>((total + 255) / 256, 16384)), dim3(256), 0, stream, frames, static_cast<char*>(out),
+                     ld_out * 2, rows, res, patch, sat_flag);
+  FC_CHECK_LAUNCH("im2col_x2");
   return FC_OK;
 }
 

@@ -43,6 +43,14 @@ struct fc_handle {
   bool packed = false;
   fc::Tower vis, txt;
   const void *conv_w = nullptr, *vproj_t = nullptr, *tproj_t = nullptr;
+  // split_gemm 2 with a patch size the im2col -> x2 pass serves: the x2 image of visual.conv1.weight as [width, 3 p^2], its scale
+  // pair and a zero bias vector (the convolution has none; the GEMM kernel starts its accumulators from one)
+  const void* conv_w2 = nullptr;
+  const float *conv_s2 = nullptr, *zero_bias = nullptr;
+  bool x2_patch() const {
+    return split2() && patch_kp() == patch_k() && cfg.vision_patch_size % 8 == 0 && cfg.image_resolution % 4 == 0 && patch_k() % 64 == 0 &&
+           patch_k() >= 128;
+  }
   // split_gemm 2: the range flag of the x2 writers - a device int in the packed-weights arena and its pinned host mirror
   // (copied behind every visual-tower call; allocated by fc_pack_weights, freed by fc_destroy)
   int* sat_flag = nullptr;
