@@ -134,6 +134,58 @@ def audit_no_scratch(asm_path: Path, substrings) -> int:
     return checked
 
 
+# gemm_split2.h issues its LDS-DMA pieces as inline asm (`s_mov_b32 m0, ...; buffer_load_dwordx4 ... offen lds`): hipcc pads no
+# hazard whose consumer sits inside an asm string (cdna_hip_programming.md section 5.7 item 2).  The one that can bite here: a VALU
+# write of an SGPR (v_readlane_b32 reloading a spilled scalar, v_readfirstlane_b32) needs 5 wait states before a VMEM instruction
+# reads that SGPR as descriptor or offset.  SALU writes are interlocked.  Checked on the generated ISA after every compile.
+ASM_DMA_AUDIT = {"gemm_split2.hip": ["gemm_split2_kernel"]}
+
+
+def audit_asm_dma_hazards(asm_path: Path, substrings) -> int:
+    """Raises if an LDS-DMA `buffer_load ... lds` of a kernel whose name contains one of `substrings` reads an SGPR whose latest
+    writer, fewer than 5 wait states upstream (straight-line scan; s_nop N counts N + 1), is a VALU instruction.  Returns the number
+    of DMA instructions checked."""
+    import re
+    text = asm_path.read_text()
+    checked = 0
+
+    def sregs(tok):
+        out = set()
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", tok):
+            out.update(range(int(a), int(b) + 1))
+        out.update(int(a) for a in re.findall(r"\bs(\d+)\b", tok))
+        return out
+
+    for m in re.finditer(r"^(\S+):\s*;\s*@", text, flags=re.M):
+        if not any(sub in m.group(1) for sub in substrings):
+            continue
+        body = text[m.end():]
+        body = body[:body.find("s_endpgm")]
+        lines = [l.split(";")[0].strip() for l in body.splitlines()]
+        lines = [l for l in lines if l and not l.endswith(":") and not l.startswith(".")]
+        for n, c in enumerate(lines):
+            if not (c.startswith("buffer_load_dword") and c.endswith(" lds")):
+                continue
+            checked += 1
+            need, states, k = sregs(c), 0, n - 1
+            while k >= 0 and states < 5 and need:
+                p = lines[k]
+                k -= 1
+                dst = re.match(r"(\S+)\s+(s\[\d+:\d+\]|s\d+)\b", p)
+                if dst:
+                    written = sregs(dst.group(2)) & need
+                    if written:
+                        if p.startswith("v_"):
+                            raise RuntimeError(f"{asm_path.name}: {m.group(1)}: `{p}` writes an SGPR {states} wait state(s) before `{c}` "
+                                               f"reads it inside an asm statement (a VALU-written SGPR needs 5 before a VMEM read)")
+                        need -= written   # an SALU write: interlocked, and it hides older writers
+                nop = re.match(r"s_nop\s+(\d+)", p)
+                states += int(nop.group(1)) + 1 if nop else 1
+    if checked == 0:
+        raise RuntimeError(f"{asm_path.name}: no LDS-DMA instruction found in {substrings} (audit out of date?)")
+    return checked
+
+
 LAB_LIB = REPO / "tools" / "bin" / "libfitclip_hip_lab.so"
 DEBUG_LIB = REPO / "tools" / "bin" / "libfitclip_hip_debug.so"
 
@@ -153,7 +205,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src.replace(".hip", ".o").replace(".cpp", ".o"))
-        audited = src in ASYNC_LOAD_AUDIT or src in NO_SCRATCH_AUDIT
+        audited = src in ASYNC_LOAD_AUDIT or src in NO_SCRATCH_AUDIT or src in ASM_DMA_AUDIT
         asm = objdir / (src.replace(".hip", "") + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
         # an audited source is compiled with -save-temps and its ISA checked on EVERY build: an up-to-date object whose .s file is
         # missing or older than the source (built before the source joined an audit table) is recompiled, never linked unaudited
@@ -172,6 +224,10 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
                     n = audit_no_scratch(asm, NO_SCRATCH_AUDIT[src])
                     if verbose:
                         print(f"{src}: {n} kernel instantiation(s) audited: no VGPR spills, no scratch", flush=True)
+                if src in ASM_DMA_AUDIT:
+                    n = audit_asm_dma_hazards(asm, ASM_DMA_AUDIT[src])
+                    if verbose:
+                        print(f"{src}: {n} inline-asm LDS-DMA instruction(s) audited: no VALU-written SGPR within 5 wait states", flush=True)
             except Exception:
                 obj.unlink(missing_ok=True)  # never link an object that failed an audit
                 raise

@@ -364,6 +364,23 @@ __device__ __forceinline__ f32x4 quick_gelu_f32x4(const f32x4 x) {
   const f32x2 lo = quick_gelu_pair(f32x2{x[0], x[1]}), hi = quick_gelu_pair(f32x2{x[2], x[3]});
   return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
+// The same function with every step spelled on all FOUR values (the two packed halves of a step are adjacent in the source): the
+// two chains of quick_gelu_f32x4 above come out of hipcc one after the other, each packed instruction waiting for its predecessor
+// (an `s_nop` after almost every one in a VALU-bound epilogue); interleaved they cover each other.  The same IEEE operations in the
+// same order per element: bit-identical to quick_gelu_f32.
+__device__ __forceinline__ f32x4 quick_gelu_f32x4_wide(const f32x4 x) {
+  constexpr float kHi = -2.4554669857025146f, kLo = 2.6109498563187117e-08f;
+  const f32x4 hi4 = {kHi, kHi, kHi, kHi}, lo4 = {kLo, kLo, kLo, kLo};
+  const f32x4 p = x * kHi;
+  const f32x4 t = {fminf(p[0], 126.f), fminf(p[1], 126.f), fminf(p[2], 126.f), fminf(p[3], 126.f)};
+  f32x4 r = __builtin_elementwise_fma(x, hi4, -p);
+  r = __builtin_elementwise_fma(x, lo4, r);
+  f32x4 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+  e = __builtin_elementwise_fma(e, r * 0.6931471805599453f, e);
+  const f32x4 d = e + 1.f;
+  const f32x4 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+  return x * s;
+}
 // d/dx [x * sigmoid(1.702 x)] = s * (1 + 1.702 x (1 - s))
 __device__ __forceinline__ float quick_gelu_grad_f32(float x) {
   const float s = sigmoid_1702(x);

@@ -58,7 +58,8 @@ constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
 // PF: activation fragments requested PF row tiles ahead (2: three register sets, 256-row tiles only)
 // PRIO (lab): 1 = waves 4..7 (the later-dispatched partner on every SIMD) at s_setprio 2 for the whole kernel; 2 = the two halves
 // take the higher priority in alternate K-steps; 3 = waves 0..3 at s_setprio 2
-template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1, int PRIO = 0>
+// GW (lab): 0 = QuickGELU as two pair chains (quick_gelu_f32x4), 1 = every step on all four values (quick_gelu_f32x4_wide; shipped)
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1, int PRIO = 0, int GW = 1>
 __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   constexpr int BM = BMT, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 (64) x 64 per wave
@@ -145,7 +146,9 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
     // ("m0" in the clobber list draws hipcc's reserved-register warning - that the register is ours to set is the point; the
     // build passes -Wno-inline-asm)
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+    // (one wait state between the SALU write of M0 and the instruction that reads it; the scalars the load reads must not come from
+    // a VALU write less than 5 wait states upstream - hipcc pads nothing inside or in front of an asm string: build.py audits the ISA)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
   };
   auto stage_piece = [&](int stage, int kt, auto IDX) {  // piece IDX (0..LPA-1 activations, then weights) of K-step kt -> stage
     constexpr int idx = decltype(IDX)::value;
@@ -462,7 +465,8 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
               f32x4 v = acc[i][2 * jp + jj] * w_inv;
-              v = quick_gelu_f32x4(v);  // (packed pairs; the bits of quick_gelu_exact)
+              if constexpr (GW) v = quick_gelu_f32x4_wide(v);  // (packed pairs, the two halves interleaved; the bits of quick_gelu_exact)
+              else v = quick_gelu_f32x4(v);
               split2(v, h1[pt & 1][jj], h2[pt & 1][jj]);
               bad = __builtin_elementwise_fma(h1[pt & 1][jj], zero4, bad);
             }
