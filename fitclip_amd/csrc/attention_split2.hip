@@ -59,7 +59,9 @@ __device__ __forceinline__ void split2x8(const f32x4& a, const f32x4& b, f16x8& 
   h1 = __builtin_bit_cast(f16x8, u32x4{w.h1, x.h1, y.h1, z.h1});
   h2 = __builtin_bit_cast(f16x8, u32x4{w.h2, x.h2, y.h2, z.h2});
 }
-// running max |x| over eight values (v_max3_f32 with |.| source modifiers: one instruction per two values)
+// running max |x| over eight values (v_max3_f32 with |.| source modifiers: one instruction per two values).  A maximum drops NaN
+// operands: this test catches finite values beyond fp16's range and infinities; a NaN among q, k, v reaches the frame's embedding
+// through the softmax and the projections and is caught by the output scan of fc_encode_image (api.hip: nonfinite_flag_kernel)
 __device__ __forceinline__ void amax8(float& m, const f32x4& a, const f32x4& b) {
   asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a[0]), "v"(a[1]));
   asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a[2]), "v"(a[3]));

@@ -108,6 +108,25 @@ __device__ __forceinline__ void split2(const f32x4& x, f16x4& h1, f16x4& h2) {
     h2[e] = static_cast<_Float16>((x[e] - static_cast<float>(h1[e])) * X2_RESID_SCALE);
   }
 }
+// The same planes in four instructions per PAIR instead of six: h1 as one packed conversion, h2 = fp16(fma(h1, -2^11, 2^11 x)) on the
+// mixed-precision fma (v_fma_mixlo / mixhi_f16 read h1 straight from the packed register and write either half of the packed h2) -
+// 2^11 x is exact, the fma's exact value 2^11 (x - h1) is representable, so its one rounding is the rounding of split2's conversion:
+// bit-identical planes.  hipcc has no builtin for the mix instructions and picks them for one pair in two at best (the other gets
+// separate conversions and a v_perm), hence inline asm; plain VALU instructions, no memory, no hazard of their own.
+__device__ __forceinline__ void split2_mix(const f32x4& x, f16x4& h1, f16x4& h2) {
+  const f32x4 xs = x * X2_RESID_SCALE;
+  unsigned a1, a2, b1, b2;
+  const float neg = -X2_RESID_SCALE;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a1) : "v"(x[0]), "v"(x[1]));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(b1) : "v"(x[2]), "v"(x[3]));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(a2) : "v"(a1), "v"(neg), "v"(xs[0]));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(b2) : "v"(b1), "v"(neg), "v"(xs[2]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a2) : "v"(a1), "v"(neg), "v"(xs[1]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(b2) : "v"(b1), "v"(neg), "v"(xs[3]));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  h1 = __builtin_bit_cast(f16x4, u32x2{a1, b1});
+  h2 = __builtin_bit_cast(f16x4, u32x2{a2, b2});
+}
 // weight planes of four values, xs = s * w: UNSCALED residual
 __device__ __forceinline__ void split2w(const f32x4& xs, f16x4& g1, f16x4& g2) {
 #pragma clang fp contract(off)

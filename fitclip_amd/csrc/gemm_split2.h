@@ -58,8 +58,9 @@ constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
 // PF: activation fragments requested PF row tiles ahead (2: three register sets, 256-row tiles only)
 // PRIO (lab): 1 = waves 4..7 (the later-dispatched partner on every SIMD) at s_setprio 2 for the whole kernel; 2 = the two halves
 // take the higher priority in alternate K-steps; 3 = waves 0..3 at s_setprio 2
-// GW (lab): 0 = QuickGELU as two pair chains (quick_gelu_f32x4), 1 = every step on all four values (quick_gelu_f32x4_wide; shipped)
-template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1, int PRIO = 0, int GW = 1>
+// GW (lab): 0 = QuickGELU as two pair chains (quick_gelu_f32x4), 1 = every step on all four values (quick_gelu_f32x4_wide),
+// 2 = 1 + the planes through the mixed-precision fma (split2_mix; shipped: c_fc at the bench size 4.442 -> 4.407 ms)
+template <int EPI, int ABL = 0, int SPREAD = 0, int RW = 4, int RR = 0, int BMT = 256, int PF = 1, int PRIO = 0, int GW = 2>
 __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   constexpr int BM = BMT, BN = 256, WM = 2, WN = 4, NW = 8;
   constexpr int TM = BM / WM, TN = BN / WN;        // 128 (64) x 64 per wave
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
               f32x4 v = acc[i][2 * jp + jj] * w_inv;
               if constexpr (GW) v = quick_gelu_f32x4_wide(v);  // (packed pairs, the two halves interleaved; the bits of quick_gelu_exact)
               else v = quick_gelu_f32x4(v);
-              split2(v, h1[pt & 1][jj], h2[pt & 1][jj]);
+              if constexpr (GW == 2) split2_mix(v, h1[pt & 1][jj], h2[pt & 1][jj]); else split2(v, h1[pt & 1][jj], h2[pt & 1][jj]);
               bad = __builtin_elementwise_fma(h1[pt & 1][jj], zero4, bad);
             }
             asm volatile("" : "+v"(bad));   // (accumulated HERE: hipcc otherwise keeps the planes alive for one reduction at the end)

@@ -82,7 +82,7 @@ void launch_m32(const GemmArgs& a, hipStream_t st) {   // the 32x32x16 kernel
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), kSplit2Lds, st, a);
 }
-template <int EPI, int ABL, int SPREAD = 0, int RW = 4, int PF = 1, int PRIO = 0, int GW = 1>
+template <int EPI, int ABL, int SPREAD = 0, int RW = 4, int PF = 1, int PRIO = 0, int GW = 2>
 void launch_k32(const GemmArgs& a, hipStream_t st) {   // the 16x16x32 kernel
   auto kern = gemm_split2_kernel<EPI, ABL, SPREAD, RW, 0, 256, PF, PRIO, GW>;
   static bool configured = false;
@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
     const int ns = sh.epi == 1 ? 4 : 0;
     if (sh.epi == 1) {
       vs = {{"m32 shipped", launch_m32<EPI_GELU_X2, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_GELU_X2, 0, 3>, ns},
-            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 spread5 gelu-pairs", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 0>, ns}, {"k32 nsplit2 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 2}, {"k32 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
+            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 spread5 gelu-pairs", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 0>, ns}, {"k32 spread5 gelu-wide plain-split", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 1>, ns}, {"k32 nsplit2 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 2}, {"k32 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_GELU_X2, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_GELU_X2, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_GELU_X2, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_GELU_X2, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_GELU_X2, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_GELU_X2, 6, 3>, ns},
