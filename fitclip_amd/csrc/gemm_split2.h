@@ -54,7 +54,8 @@ constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
 
 // ABL (tools/x2k_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 3 = no epilogue; 6 = no loads, no waits, no
 // epilogue (MFMA + LDS reads only); 4 = the real kernel with s_memtime stamps around the hand-over wait, the hand-over barrier, the
-// K loop and the epilogue, summed per wave into g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).  RW: residual rows requested RW patches (16 rows x 32 columns) ahead (EPI_RESID3_F32).
+// K loop and the epilogue, summed per wave into g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).
+// RW: residual / positional-embedding rows requested RW patches (16 rows x 32 columns) ahead (EPI_RESID3_F32, EPI_PATCH_F32).
 // PF: activation fragments requested PF row tiles ahead (2: three register sets, 256-row tiles only)
 // PRIO (lab): 1 = waves 4..7 (the later-dispatched partner on every SIMD) at s_setprio 2 for the whole kernel; 2 = the two halves
 // take the higher priority in alternate K-steps; 3 = waves 0..3 at s_setprio 2
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- tile schedule (gemm_split2_kernel's)
+  // ---- tile schedule (gemm_split3_kernel's): XCD x (= blockIdx & 7) owns a contiguous range of M-panels (optionally only 1 / nsplit
+  // of the N range: the weights of its column tiles then stay in its L2); its workgroups stride through that range in N-fastest order
   const int tilesN = (g.N + BN - 1) / BN;
   const int tilesM = (g.M + BM - 1) / BM;
   const int G = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;

@@ -71,6 +71,18 @@ __global__ void check(const float* A, const float* W, const float* bias, const v
   out[2 * s + 1] = got;
 }
 
+// what v_mfma_f32_16x16x32_f16 does with subnormal fp16 inputs: D = A(all = a) x B(all = b), k = 32 products per element
+__global__ void denorm_probe(float a, float b, float* out) {
+  f16x8 va, vb;
+  for (int e = 0; e < 8; ++e) { va[e] = static_cast<_Float16>(a); vb[e] = static_cast<_Float16>(b); }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, vb, acc, 0, 0, 0);
+  if (threadIdx.x == 0) {
+    out[0] = acc[0];
+    out[1] = (float)static_cast<_Float16>(a);
+  }
+}
+
 template <int EPI, int ABL, int SPREAD = 0, int RW = 2, int RR = 0>
 void launch_m32(const GemmArgs& a, hipStream_t st) {   // the 32x32x16 kernel
   auto kern = gemm_split2_m32_kernel<EPI, ABL, SPREAD, RW, RR>;
@@ -105,6 +117,20 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
+  {
+    float* d;
+    HIP_OK(hipMalloc(&d, 64));
+    const float cases[][2] = {{1.f, 1.f}, {3.0e-5f, 1024.f}, {6.0e-8f, 16384.f}, {3.0e-5f, 3.0e-5f}, {1.0e-3f, 1.f}};
+    for (auto& c : cases) {
+      denorm_probe<<<1, 64, 0, st>>>(c[0], c[1], d);
+      float h[2];
+      HIP_OK(hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      printf("denorm probe (16x16x32): a=%g (fp16 %g) b=%g: mfma sum of 32 products = %.9g, expected %.9g\n", c[0], h[1], c[1], h[0],
+             32.0 * (double)h[1] * (double)(float)(_Float16)c[1]);
+    }
+    HIP_OK(hipFree(d));
+  }
   struct Shape { const char* name; int N, K, epi; };   // epi: 0 = fp32 rows out, 1 = QuickGELU + plane rows out, 2 = residual update
   const Shape shapes[] = {{"qkv", 2304, 768, 0}, {"out_proj", 768, 768, 2}, {"c_fc", 3072, 768, 1}, {"c_proj", 768, 3072, 2}};
   for (const Shape& sh : shapes) {
