@@ -445,14 +445,32 @@ SPLIT_MODES = {
     "fp32x3": (3, 2, {6: "bias_f32_out", 10: "bias_quickgelu_x2_out", 8: "bias_residual_f32_out"}, "fp16",
                "gemm_split2_kernel<256x256><two fp16 planes per operand, three MFMA products per fp32 product, {epi}>",
                "fp32 values as two fp16 numbers (x = h1 + 2^-11 h2; weights with a power-of-two scale per tensor); three fp16 MFMA "
-               "products per fp32 product, fp32 accumulate (the visual tower's block GEMMs); its attention products: {attention}; "
-               "LayerNorm, softmax arithmetic, residual stream, patch embedding and the text tower in plain fp32"),
+               "products per fp32 product, fp32 accumulate ({gemms}); the visual tower's attention products: {attention}; "
+               "LayerNorm, softmax arithmetic, residual stream, the text tower's attention and everything not named here in plain fp32"),
     "fp32x6": (6, 1, {6: "bias_f32_out", 7: "bias_quickgelu_x3_out", 8: "bias_residual_f32_out"}, "bf16",
                "gemm_split3_kernel<256x256><three bf16 planes per operand, six MFMA products per fp32 product, {epi}>",
-               "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate (the visual "
-               "tower's block GEMMs); its attention products: {attention}; LayerNorm, softmax arithmetic, residual stream, patch "
-               "embedding and the text tower in plain fp32"),
+               "fp32 values as three bf16 numbers; six bf16 MFMA products per fp32 product, fp32 accumulate ({gemms}); the visual "
+               "tower's attention products: {attention}; LayerNorm, softmax arithmetic, residual stream, the text tower's attention "
+               "and everything not named here in plain fp32"),
 }
+
+
+def gemm_description(records, dims, prec_code: int, nprod: int) -> str:
+    """Which GEMMs of an instrumented step ran on the mode's plane kernels, from the library's own records (kind 0; .precision = the
+    pipe code, .epilogue, .N, .K = products x the fp32 K): the visual tower's block GEMMs, its patch embedding (epilogue 3) and the text
+    tower's block GEMMs (fp32x3 runs them that way in calls of >= 4096 token rows: csrc/api.hip kTextX2MinRows)."""
+    vw, tw = dims.vision_width, dims.transformer_width
+    mine = [r for r in records if r["kind"] == 0 and r["precision"] == prec_code]
+    def blocks(w):
+        return any(r["epilogue"] in (6, 7, 8, 10) and r["K"] in (nprod * w, nprod * 4 * w) and r["N"] in (3 * w, w, 4 * w) for r in mine)
+    parts = []
+    if blocks(vw):
+        parts.append("the visual tower's block GEMMs")
+    if any(r["epilogue"] == 3 for r in mine):
+        parts.append("its patch embedding")
+    if tw != vw and blocks(tw):
+        parts.append("the text tower's block GEMMs")
+    return ", ".join(parts) or "no GEMM recorded"
 
 
 def run_split_mode(sd, video, text, args, shards, device, backend, precision="fp32x3"):
@@ -498,7 +516,7 @@ def run_split_mode(sd, video, text, args, shards, device, backend, precision="fp
     return {
         "precision": precision,
         "value": round(shards.n_total * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": dtype.format(attention=attention_description(
+        "dtype": dtype.format(gemms=gemm_description(records, enc.model.dims, prec_code, nprod), attention=attention_description(
             records, (enc.model.dims.image_resolution // enc.model.dims.vision_patch_size) ** 2 + 1)),
         "roofline": {"bound": "mfma", "kernel": kernel_fmt.format(epi=epi_name) + f" M={M} N={N} K={K6 // nprod} (x {nprod} products)",
                      "achieved": round(pipe_flops * cnt / (ms * 1e-3) / 1e12, 1), "peak": PEAK_TFLOPS[pipe], "unit": "TFLOP/s",

@@ -143,6 +143,13 @@ std::vector<PackItem> packed_list(const fc_handle* h) {
         l.push_back({b + n, h->split2() ? PACK_SPLIT2 : PACK_SPLIT3});
     }
   }
+  if (h->x2_text()) {  // split_gemm 2: the text tower's block weights too (large calls run them on the fp16 pipe: fc_encode_text)
+    for (int i = 0; i < h->cfg.transformer_layers; ++i) {
+      const std::string b = "transformer.resblocks." + std::to_string(i);
+      for (const char* n : {".attn.in_proj_weight", ".attn.out_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight"})
+        l.push_back({b + n, PACK_SPLIT2});
+    }
+  }
   if (h->x2_patch()) l.push_back({"visual.conv1.weight", PACK_SPLIT2});   // [width, 3, p, p] = [width, 3 p^2] rows
   l.push_back({"visual.proj", PACK_TRANSPOSE});
   l.push_back({"text_projection", PACK_TRANSPOSE});
@@ -241,6 +248,25 @@ __global__ void __launch_bounds__(256) nonfinite_flag_kernel(const float* __rest
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     bad |= (__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u;
   if (bad) atomicOr(flag, 1);
+}
+
+// The end of a tower call that wrote fp16 planes: the output scan, the flag's copy to its pinned mirror (no synchronisation: the
+// NEXT call and fc_range_status read it) and - fc_range_strict - the wait that makes THIS call answer for its own values.
+int finish_range(fc_handle* h, const float* out, size_t total, hipStream_t st, const char* who) {
+  if (h->sat_flag) {
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256)), dim3(256), 0, st, out, total, h->sat_flag);
+    FC_CHECK_LAUNCH("output scan");
+    if (hipMemcpyAsync(h->sat_host, h->sat_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+      return fail(FC_ELAUNCH, "%s: range flag copy", who);
+  }
+  FC_DEBUG_SCAN(out, total, st, who);
+  if (h->sat_flag && h->strict_range) {   // one host synchronisation
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(FC_ELAUNCH, "%s: synchronise for the range flag", who);
+    if (*h->sat_host)
+      return fail(FC_ERANGE, "%s: an activation (or a weight) beyond fp16's range (65504) or not finite was met: split_gemm = 2 "
+                             "cannot represent this model's values; the embeddings of this call are not valid", who);
+  }
+  return FC_OK;
 }
 
 struct Scratch {
@@ -454,16 +480,27 @@ int gemm_x2(fc_handle* h, int epi, const void* A2, const void* W2, const float* 
 
 bool x2_pass_ok(int M, int w) { return M > 0 && w >= 128 && w % 64 == 0; }
 
-int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, const float* fin_w,
-                  const float* fin_b, long pool_step, hipStream_t st, const TowerEntry& entry) {
+// The text tower (width 512 in every CLIP the reference loads: N = 512 gives the 256 x 256-tile kernel two tile columns) joins
+// split_gemm 2 per CALL, from this many token rows on.  Measured (tools/text_gemm_x2_probe.py, the four GEMMs of a block, fp32
+// kernels -> three-product kernel): 256 captions = 19 712 rows 1032 -> 387 us; 32 captions = 2 464 rows 191 -> 212 us - too few
+// tiles for 256 CUs, where the fp32 path's 64-row tiles still fill the chip.
+constexpr long kTextX2MinRows = 4096;
+bool text_x2_call(const fc_handle* h, int n) {
+  return h->x2_text() && x2_pass_ok(n, h->cfg.transformer_width) && (long)n * h->cfg.context_length >= kTextX2MinRows;
+}
+
+int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int S, int w, int heads, int causal, const float* fin_w,
+                  const float* fin_b, const int* pool_idx, long pool_step, hipStream_t st, const TowerEntry* entry) {
   const int M = n_seq * S;
   const long ld2 = x2_row_elems(w);
   const size_t nl = t.blocks.size();
   for (size_t l = 0; l < nl; ++l) {
     const Block& b = t.blocks[l];
-    if (l == 0) {
-      FC_TRY(launch_layernorm_pair(s.x, entry.cls, entry.pos0, S, entry.pre_w, entry.pre_b, b.ln1_w, b.ln1_b, s.xn,
+    if (l == 0 && entry) {
+      FC_TRY(launch_layernorm_pair(s.x, entry->cls, entry->pos0, S, entry->pre_w, entry->pre_b, b.ln1_w, b.ln1_b, s.xn,
                                    KIND_X2, M, w, st));
+    } else if (l == 0) {
+      FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld2, KIND_X2, M, w, st));
     } else {
       ProfScope ps(h, st, 2, M, w, 1);
       FC_TRY(launch_layernorm(s.x, w, nullptr, b.ln1_w, b.ln1_b, s.xn, ld2, KIND_X2, M, w, st));
@@ -471,12 +508,12 @@ int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
     FC_TRY(gemm_x2(h, EPI_BIAS_F32, s.xn, b.in_w2, b.in_s2, b.in_b, s.big, M, 3 * w, w, 3 * w, st));
     {
       ProfScope ps(h, st, 1, n_seq, heads, S);
-      if (attention_split2_supported(S, 0)) {
+      if (attention_split2_supported(S, causal)) {
         ps.form(ATTN_SPLIT2);
         FC_TRY(launch_attention_split2(s.big, s.xn, n_seq, S, heads, st, h->sat_flag));
-      } else {  // other sequence lengths: the fp32 kernel of that length, then the split as a pass of its own
+      } else {  // other sequence lengths, causal attention: the fp32 kernel of that form, then the split as a pass of its own
         ps.form(PREC_F32, 1);
-        FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, 0, st));
+        FC_TRY(launch_attention(PREC_F32, s.big, s.d, n_seq, S, heads, causal, st));
         FC_TRY(launch_split2_rows(s.d, w, s.xn, ld2, M, w, h->sat_flag, st));
       }
     }
@@ -488,7 +525,7 @@ int run_blocks_x2(fc_handle* h, const Tower& t, const Scratch& s, int n_seq, int
     FC_TRY(gemm_x2(h, EPI_GELU_X2, s.xn, b.fc_w2, b.fc_s2, b.fc_b, s.big, M, 4 * w, w, (int)x2_row_elems(4 * w), st));
     FC_TRY(gemm_x2(h, EPI_RESID3_F32, s.big, b.proj_w2, b.proj_s2, b.proj_b, s.x, M, w, 4 * w, w, st));
   }
-  return launch_layernorm(s.x, pool_step * w, nullptr, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
+  return launch_layernorm(s.x, pool_idx ? w : pool_step * w, pool_idx, fin_w, fin_b, s.clsn, w, PREC_F32, n_seq, w, st);
 }
 
 // Items per pass of a tower over `n` items: what bounds a pass is only the workspace it needs (3.6 MB per ViT-B/16 frame in
@@ -511,7 +548,7 @@ int planned_chunk(const fc_handle* h, int tower, int n) {
 size_t per_item_bytes(const fc_handle* h, int tower) {
   const fc_config& c = h->cfg;
   if (tower == 0) return carve(nullptr, 1, h->vtokens(), c.vision_width, h->esz, h->patch_kp(), h->cfg.precision == FC_PREC_F32 ? h->cfg.split_gemm : 0).total;
-  return carve(nullptr, 1, c.context_length, c.transformer_width, h->esz, 0).total;
+  return carve(nullptr, 1, c.context_length, c.transformer_width, h->esz, 0, h->x2_text() ? 2 : 0).total;
 }
 
 }  // namespace
@@ -690,6 +727,11 @@ int fc_pack_weights(fc_handle* h, void* arena, size_t bytes, fc_stream stream) {
       FC_TRY(launch_x2_ln_bound(k.ln1_w, k.ln1_b, h->cfg.vision_width, h->sat_flag, stream));
       FC_TRY(launch_x2_ln_bound(k.ln2_w, k.ln2_b, h->cfg.vision_width, h->sat_flag, stream));
     }
+    if (h->x2_text())
+      for (const Block& k : h->txt.blocks) {
+        FC_TRY(launch_x2_ln_bound(k.ln1_w, k.ln1_b, h->cfg.transformer_width, h->sat_flag, stream));
+        FC_TRY(launch_x2_ln_bound(k.ln2_w, k.ln2_b, h->cfg.transformer_width, h->sat_flag, stream));
+      }
   } else {
     h->sat_flag = nullptr;
   }
@@ -713,7 +755,7 @@ size_t fc_workspace_bytes(const fc_handle* h, int32_t tower, int32_t n) {
   const int c = std::min(n, planned_chunk(h, tower, n));
   const fc_config& k = h->cfg;
   return tower == 0 ? carve(nullptr, c, h->vtokens(), k.vision_width, h->esz, h->patch_kp(), h->cfg.precision == FC_PREC_F32 ? h->cfg.split_gemm : 0).total
-                    : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0).total;
+                    : carve(nullptr, c, k.context_length, k.transformer_width, h->esz, 0, h->x2_text() ? 2 : 0).total;
 }
 
 int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, void* ws, size_t ws_bytes,
@@ -765,8 +807,8 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     const TowerEntry entry{h->w("visual.class_embedding"), h->w("visual.positional_embedding"),
                            h->w("visual.ln_pre.weight"), h->w("visual.ln_pre.bias")};
     if (split == 2 && x2_pass_ok(cn * T, vw)) {
-      FC_TRY(run_blocks_x2(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
-                           h->w("visual.ln_post.bias"), T, st, entry));
+      FC_TRY(run_blocks_x2(h, h->vis, s, cn, T, vw, h->vheads(), 0, h->w("visual.ln_post.weight"),
+                           h->w("visual.ln_post.bias"), nullptr, T, st, &entry));
     } else if (split == 1 && x3_pass_ok(cn * T, vw)) {
       FC_TRY(run_blocks_x3(h, h->vis, s, cn, T, vw, h->vheads(), h->w("visual.ln_post.weight"),
                            h->w("visual.ln_post.bias"), T, st, entry));
@@ -777,22 +819,7 @@ int fc_encode_image(fc_handle* h, const float* frames, int32_t n, float* out, vo
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->vproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, vw, c.embed_dim, 0, st));
   }
-  if (h->sat_flag) {
-    const size_t total = (size_t)n * c.embed_dim;
-    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256)), dim3(256), 0, st, out, total, h->sat_flag);
-    FC_CHECK_LAUNCH("fc_encode_image: output scan");
-  }
-  // the range flag follows the call to the host (pinned: no synchronisation; the NEXT call and fc_range_status read it)
-  if (h->sat_flag && hipMemcpyAsync(h->sat_host, h->sat_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
-    return fail(FC_ELAUNCH, "fc_encode_image: range flag copy");
-  FC_DEBUG_SCAN(out, (size_t)n * c.embed_dim, st, "fc_encode_image");
-  if (h->sat_flag && h->strict_range) {   // fc_range_strict: THIS call answers for its own values (one host synchronisation)
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(FC_ELAUNCH, "fc_encode_image: synchronise for the range flag");
-    if (*h->sat_host)
-      return fail(FC_ERANGE, "fc_encode_image: an activation (or a weight) beyond fp16's range (65504) or not finite was met: split_gemm = 2 "
-                             "cannot represent this model's values; the embeddings of this call are not valid");
-  }
-  return FC_OK;
+  return finish_range(h, out, (size_t)n * c.embed_dim, st, "fc_encode_image");
 }
 
 int fc_range_strict(fc_handle* h, int32_t on) {
@@ -820,23 +847,36 @@ int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n, float* out, void
   if (((uintptr_t)out | (uintptr_t)ws) & 15) return fail(FC_EINVAL, "fc_encode_text: unaligned pointer");
   const fc_config& c = h->cfg;
   const int tw = c.transformer_width, L = c.context_length;
+  // split_gemm 2: one arithmetic per CALL - a call of kTextX2MinRows token rows or more runs the four block GEMMs on the fp16 pipe
+  // (all of its passes, also a short last one), a smaller call the fp32 kernels
+  const int split = text_x2_call(h, n) ? 2 : 0;
+  if (split && h->sat_host && *h->sat_host)
+    return fail(FC_ERANGE, "fc_encode_text: an earlier call met an activation (or LayerNorm weights) beyond fp16's range (65504): "
+                           "split_gemm = 2 cannot represent this model's values; its results since then are not valid");
+  const int carve_split = h->x2_text() ? 2 : 0;   // the layout fc_workspace_bytes sized: the same for both kinds of call
   const size_t per = per_item_bytes(h, 1);
   int chunk = std::min(n, planned_chunk(h, 1, n));
-  if (carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) {
+  if (carve(nullptr, chunk, L, tw, h->esz, 0, carve_split).total > ws_bytes) {
     chunk = (int)std::min<size_t>(chunk, ws_bytes / std::max<size_t>(1, per / 2));
-    while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0).total > ws_bytes) --chunk;
+    while (chunk > 0 && carve(nullptr, chunk, L, tw, h->esz, 0, carve_split).total > ws_bytes) --chunk;
   }
   if (chunk <= 0) return fail(FC_ENOMEM, "fc_encode_text: workspace too small (need >= %zu bytes)", per + 2048);
   for (int off = 0; off < n; off += chunk) {
     const int cn = std::min(chunk, n - off);
-    const Scratch s = carve(static_cast<char*>(ws), cn, L, tw, h->esz, 0);
+    const Scratch s = carve(static_cast<char*>(ws), cn, L, tw, h->esz, 0, carve_split);
     FC_TRY(launch_text_embed(ids + (size_t)off * L, h->w("token_embedding.weight"), h->w("positional_embedding"), s.x,
                              s.eot, cn, L, tw, c.vocab_size, st));
-    FC_TRY(run_blocks(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, h->w("ln_final.weight"),
-                      h->w("ln_final.bias"), s.eot, 0, st));
+    if (split) {
+      FC_TRY(run_blocks_x2(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, h->w("ln_final.weight"), h->w("ln_final.bias"),
+                           s.eot, 0, st, nullptr));
+    } else {
+      FC_TRY(run_blocks(h, h->txt, s, cn, L, tw, c.transformer_heads, 1, h->w("ln_final.weight"),
+                        h->w("ln_final.bias"), s.eot, 0, st));
+    }
     FC_TRY(gemm(h, EPI_STORE_F32, s.clsn, h->tproj_t, nullptr, out + (size_t)off * c.embed_dim, nullptr, cn,
                 c.embed_dim, tw, c.embed_dim, 0, st));
   }
+  if (split) return finish_range(h, out, (size_t)n * c.embed_dim, st, "fc_encode_text");
   FC_DEBUG_SCAN(out, (size_t)n * c.embed_dim, st, "fc_encode_text");
   return FC_OK;
 }

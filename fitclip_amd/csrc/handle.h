@@ -51,8 +51,11 @@ struct fc_handle {
     return split2() && patch_kp() == patch_k() && cfg.vision_patch_size % 8 == 0 && cfg.image_resolution % 4 == 0 && patch_k() % 64 == 0 &&
            patch_k() >= 128;
   }
+  // split_gemm 2 also serves the text tower's four block GEMMs (x2 images of its weights are packed) when its width has the
+  // kernels' granularity; which CALLS use them is fc_encode_text's decision (api.hip: kTextX2MinRows)
+  bool x2_text() const { return split2() && cfg.transformer_width % 256 == 0 && cfg.transformer_layers > 0; }
   // split_gemm 2: the range flag of the x2 writers - a device int in the packed-weights arena and its pinned host mirror
-  // (copied behind every visual-tower call; allocated by fc_pack_weights, freed by fc_destroy)
+  // (copied behind every tower call that wrote fp16 planes; allocated by fc_pack_weights, freed by fc_destroy)
   int* sat_flag = nullptr;
   int* sat_host = nullptr;
   bool strict_range = false;  // fc_range_strict: fc_encode_image waits for its own flag copy and returns FC_ERANGE itself

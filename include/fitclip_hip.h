@@ -83,11 +83,16 @@ typedef struct {
                                  patch embedding, the text tower and passes too small for that GEMM stay on the plain
                                  fp32 path.  2: the same GEMMs on the fp16 matrix cores over TWO-plane operands ("x2" rows,
                                  fc_split2: x = h1 + 2^-11 h2 in fp16) with THREE products per fp32 product
-                                 (fc_gemm_split2) - fp32 accuracy at ~2.7x the fp32-MFMA rate.  fp16 planes hold
+                                 (fc_gemm_split2) - fp32 accuracy at ~2.7x the fp32-MFMA rate; so does the patch embedding
+                                 (patch sizes that are multiples of 8) and, in an fc_encode_text CALL of 4096 token rows or
+                                 more (54 captions of 77 tokens; text widths that are multiples of 256), the four block
+                                 GEMMs of the text tower - a smaller call cannot fill the chip with that kernel's tiles and
+                                 keeps the fp32 kernels: one arithmetic per call, rows independent of the rest of the call
+                                 within either kind.  fp16 planes hold
                                  |x| <= 65504: a value beyond that (or an infinite / NaN value or weight) raises a device-side
-                                 flag and the NEXT fc_encode_image (and fc_range_status) returns FC_ERANGE.  A caller MUST ask
-                                 fc_range_status(wait = 1) after its last batch before it uses or saves the embeddings - or
-                                 switch fc_range_strict on, and every fc_encode_image answers for itself (one host
+                                 flag and the NEXT fc_encode_image / large fc_encode_text (and fc_range_status) returns
+                                 FC_ERANGE.  A caller MUST ask fc_range_status(wait = 1) after its last batch before it uses
+                                 or saves the embeddings - or switch fc_range_strict on, and every such call answers for itself (one host
                                  synchronisation per call) - never silently wrong.
                                  0 (default): fp32-input MFMA everywhere */
 } fc_config;
@@ -126,13 +131,13 @@ FC_API int fc_encode_image(fc_handle* h, const float* frames, int32_t n_frames, 
 FC_API int fc_encode_text(fc_handle* h, const int64_t* ids, int32_t n_texts, float* out, void* workspace,
                    size_t workspace_bytes, fc_stream stream);
 /* split_gemm = 2 only (FC_OK otherwise): FC_ERANGE when a writer of fp16 planes met a value beyond 65504 since
- * fc_pack_weights (activations of the visual tower's blocks; or LayerNorm weights whose outputs could exceed it).  wait != 0:
+ * fc_pack_weights (activations of the towers' blocks; or LayerNorm weights whose outputs could exceed it).  wait != 0:
  * first waits for the work queued on `stream` (one host synchronisation - call it after the last batch of an evaluation);
  * wait == 0: what the flag copies of the calls completed so far have shown (fc_encode_image itself checks this on entry). */
 FC_API int fc_range_status(fc_handle* h, fc_stream stream, int32_t wait);
-/* on != 0: every fc_encode_image of a split_gemm = 2 handle waits for its own range flag before it returns (one host
- * synchronisation per call; not capturable into a hipGraph) and returns FC_ERANGE ITSELF when its values left fp16's range.
- * Off by default: the flag is then reported by the NEXT fc_encode_image and by fc_range_status. */
+/* on != 0: every fc_encode_image (and every fc_encode_text that uses fp16 planes) of a split_gemm = 2 handle waits for its own
+ * range flag before it returns (one host synchronisation per call; not capturable into a hipGraph) and returns FC_ERANGE ITSELF
+ * when its values left fp16's range.  Off by default: the flag is then reported by the NEXT such call and by fc_range_status. */
 FC_API int fc_range_strict(fc_handle* h, int32_t on);
 
 /* Eval transform on the device (clip_video_text_encoder.py:125-133): frames dev uint8 [n, H, W, 3]

@@ -315,7 +315,7 @@ def test_towers_match_reference_fixtures(golden_dir, tag, dims, request):
         assert np.abs(img.cpu().numpy() - g[f"image_features_{ref}"]).max() < F32_TOL * scale, ref
     assert float((img - plain.encode_image(frames)).abs().max()) < 2e-6 * scale       # next to the fp32-MFMA path
     ids = torch.from_numpy(g["ids"]).to(DEV)
-    assert torch.equal(model.encode_text(ids), plain.encode_text(ids))                 # the text tower IS the fp32 path
+    assert torch.equal(model.encode_text(ids), plain.encode_text(ids))                 # (a call below 4096 token rows: the fp32 kernels)
 
 
 def test_evaluate_goldens_in_three_product_mode(golden_dir, vitb16_state_dict):
@@ -540,6 +540,55 @@ def test_strict_range_makes_every_call_answer_for_itself(tiny_state_dict):
     deferred.encode_image(frames)                                  # default: rc 0 here ...
     with pytest.raises(_lib.FitclipHipError, match="fp16"):
         deferred.check_range()                                     # ... and the consumer's check raises
+
+
+def test_text_tower_joins_the_mode_for_large_calls(vitb16_state_dict):
+    """fc_encode_text in fp32x3: a call of >= 4096 token rows (54 captions of 77 tokens) runs the text blocks' four GEMMs on the
+    three-product kernel, a smaller call the fp32 kernels (too few 256-row tiles for 256 CUs).  One arithmetic per CALL: a small call has
+    the fp32 path's bits, a large one its values at fp32 accuracy, and rows depend neither on the batch nor on the pass size."""
+    from oracle import clip_oracle as O
+    d = synth.VIT_B_16
+    split = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV)
+    plain = build_clip(vitb16_state_dict, precision="fp32", device=DEV)
+    ids = torch.from_numpy(synth.make_text(300, d, seed=5)).to(DEV)
+    assert torch.equal(split.encode_text(ids[:53]), plain.encode_text(ids[:53]))        # 4081 rows: the fp32 kernels
+    big, ref = split.encode_text(ids), plain.encode_text(ids)
+    split.check_range()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((big - ref).abs().max()) < 2e-6 * scale
+    assert not torch.equal(big, ref)                                                     # (it IS the other arithmetic)
+    assert torch.equal(split.encode_text(ids[:54]), big[:54])                            # 4158 rows: same bits in any large batch
+    passes = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV, chunk_texts=128)
+    assert torch.equal(passes.encode_text(ids), big)                                     # passes of 128, 128, 44 captions
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in O.to_torch(vitb16_state_dict).items()}
+    with torch.inference_mode():
+        truth = O.encode_text_tokens(sd64, ids[:54].cpu())
+    err3 = float((big[:54].cpu().double() - truth).abs().max())
+    err1 = float((ref[:54].cpu().double() - truth).abs().max())
+    print(f"text tower, max |features - float64 truth|: fp32x3 {err3:.3e}, fp32 {err1:.3e}")
+    assert err3 < 2e-6 * scale and err3 <= 2.0 * err1 + 1e-7 * scale
+
+
+def test_text_tower_answers_for_fp16s_range_when_it_uses_it(vitb16_state_dict):
+    """A text block whose QuickGELU output no fp16 plane can hold: a small call (fp32 kernels) is unaffected, a large call raises the flag,
+    with `strict_range` from the call itself."""
+    d = synth.VIT_B_16
+    hot_sd = _copy_sd(vitb16_state_dict)
+    key = "transformer.resblocks.1.mlp.c_fc.bias"
+    hot_sd[key] = hot_sd[key] + 1.0e5
+    ids = torch.from_numpy(synth.make_text(64, d, seed=6)).to(DEV)
+    hot = build_clip(hot_sd, precision="fp32x3", device=DEV)
+    plain = build_clip(hot_sd, precision="fp32", device=DEV)
+    assert torch.equal(hot.encode_text(ids[:8]), plain.encode_text(ids[:8]))
+    hot.check_range()                                              # nothing entered an fp16 plane
+    hot.encode_text(ids)                                           # default: rc 0 here ...
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.check_range()                                          # ... and the consumer's check raises
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        hot.encode_text(ids)                                       # so does the next call that would use the planes
+    strict = build_clip(hot_sd, precision="fp32x3", device=DEV, strict_range=True)
+    with pytest.raises(_lib.FitclipHipError, match="fp16"):
+        strict.encode_text(ids)
 
 
 def test_predict_saves_nothing_when_the_last_batch_left_fp16s_range(tmp_path, tiny_state_dict, capsys):
