@@ -458,7 +458,7 @@ SPLIT_MODES = {
 def gemm_description(records, dims, prec_code: int, nprod: int) -> str:
     """Which GEMMs of an instrumented step ran on the mode's plane kernels, from the library's own records (kind 0; .precision = the
     pipe code, .epilogue, .N, .K = products x the fp32 K): the visual tower's block GEMMs, its patch embedding (epilogue 3) and the text
-    tower's block GEMMs (fp32x3 runs them that way in calls of >= 4096 token rows: csrc/api.hip kTextX2MinRows)."""
+    tower's block GEMMs (fp32x3 runs them that way in calls of >= 2048 token rows: csrc/api.hip kTextX2MinRows)."""
     vw, tw = dims.vision_width, dims.transformer_width
     mine = [r for r in records if r["kind"] == 0 and r["precision"] == prec_code]
     def blocks(w):

@@ -482,9 +482,10 @@ bool x2_pass_ok(int M, int w) { return M > 0 && w >= 128 && w % 64 == 0; }
 
 // The text tower (width 512 in every CLIP the reference loads: N = 512 gives the 256 x 256-tile kernel two tile columns) joins
 // split_gemm 2 per CALL, from this many token rows on.  Measured (tools/text_gemm_x2_probe.py, the four GEMMs of a block, fp32
-// kernels -> three-product kernel): 256 captions = 19 712 rows 1032 -> 387 us; 32 captions = 2 464 rows 191 -> 212 us - too few
-// tiles for 256 CUs, where the fp32 path's 64-row tiles still fill the chip.
-constexpr long kTextX2MinRows = 4096;
+// kernels -> three-product kernel): 256 captions = 19 712 rows 1027 -> 341 us; 32 captions = 2 464 rows 192 -> 128 us; 24 captions
+// 135 -> 125; 16 captions 117 -> 125 (+ the split pass behind the causal attention): below ~2000 rows a launch is ONE tile's latency
+// (c_proj: 32 K-steps = 66 us whatever the row count), which the fp32 path's 64-row tiles undercut.
+constexpr long kTextX2MinRows = 2048;
 bool text_x2_call(const fc_handle* h, int n) {
   return h->x2_text() && x2_pass_ok(n, h->cfg.transformer_width) && (long)n * h->cfg.context_length >= kTextX2MinRows;
 }

@@ -11,6 +11,15 @@ namespace {
 constexpr int split2_lds(int bm) { return 2 * (bm + 256) * 128 + 8 * 2048 + 2048; }  // two stages, eight patches, two bias slices
 [[maybe_unused]] constexpr int kSplit2Lds = split2_lds(256);   // (tools/split2_lab)
 
+// tiles of the busiest XCD under the kernel's schedule (gemm_split2.h: an XCD owns ceil(panels / (8 / groups)) M-panels of 1 / groups of
+// the column tiles)
+int x2_xcd_tiles(int M, int N, int bmt, int nsplit) {
+  const int tilesM = (M + bmt - 1) / bmt, tilesN = (N + 255) / 256;
+  const int ngrp = (nsplit > 1 && 8 % nsplit == 0 && tilesN % nsplit == 0) ? nsplit : 1;
+  const int nx = 8 / ngrp;
+  return ((tilesM + nx - 1) / nx) * (tilesN / ngrp);
+}
+
 template <int EPI, int RW, int BMT>
 int launch_x2_tiles(const GemmArgs& a, hipStream_t stream) {
   // SPREAD = 5: the LDS-DMA pieces of a K-step are issued 3, 3, 2 behind the first three MFMA groups of the step before it is
@@ -20,32 +29,41 @@ int launch_x2_tiles(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = split2_lds(BMT);
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split2: cannot raise dynamic LDS to %d bytes", lds);
-  const int tiles = ((a.M + BMT - 1) / BMT) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), lds, stream, a);
+  // workgroups: the kernel's schedule gives every XCD (blockIdx & 7) a contiguous range of M-panels, so a launch with fewer tiles
+  // than CUs needs as many workgroups per XCD as its BUSIEST XCD has tiles - min(tiles, CUs) left that XCD with a second round (20
+  // panels x 2 column tiles on 40 workgroups: 6 tiles for 5 workgroups).  Workgroups without a tile return at once.
+  hipLaunchKernelGGL(kern, dim3(std::min(8 * x2_xcd_tiles(a.M, a.N, BMT, a.nsplit), device_cus())), dim3(512), lds, stream, a);
   FC_CHECK_LAUNCH("gemm_split2");
   return FC_OK;
 }
 
-// Tile height.  The kernel is persistent over 256 x 256 tiles; a launch with fewer such tiles than compute units leaves CUs idle,
-// and 128-row tiles (half the MFMAs per staged weight tile: ~0.87 of the big tile's efficiency) then double the number of busy
-// CUs: out_proj of a 32-frame call (6304 rows, 75 tiles) 0.098 -> 0.068 ms, c_proj 0.313 -> 0.229, QKV 0.098 -> 0.074
-// (tools/x2_cut_probe.py, profiles/r05_x2_cut_probe.log).  Above that the big tile wins - also where a round model says it should
-// not: at 25 216 rows (the reference-shaped call of 128 frames) out_proj is 297 tiles = "two rounds for 1.16 rounds of work", yet
-// 256-row tiles take 0.129 ms, 128-row tiles 0.121, and the fp32 kernel's remedy - a head of whole rounds plus a tail launch of
-// half tiles - 0.191: this kernel runs at the chip's power limit (1.6 - 1.8 GHz, matrix pipe busy 0.6 - 0.7), the CUs that still
-// hold tiles speed up when the others run dry, and a second launch only adds its fill and drain.  No head + tail cut here.
+// Tile height.  The kernel is persistent over 256 x 256 tiles; a launch with fewer such tiles than compute units leaves CUs idle, and
+// 128-row tiles (half the MFMAs per staged weight tile: ~0.87 of the big tile's efficiency) then double the number of busy CUs.  Below
+// one round of big tiles the choice is by rounds of the busiest XCD (cus / 8 workgroups each): one round of half tiles beats one round of
+// big tiles, one round of big tiles beats two rounds of half tiles (2 x 0.5 / 0.87).  tools/x2_cut_probe.py on the balanced grid
+// (profiles/r06_x2_cut_probe.log; ms per launch, 256-row / 128-row tiles): a 32-frame call (6304 rows) QKV 0.096 / 0.066, out_proj 0.050 /
+// 0.035, c_proj 0.151 / 0.105; 12 608 rows out_proj 0.055 / 0.070, c_proj 0.162 / 0.219; the text tower at 256 captions (19 712 rows x
+// 768) out_proj 0.068 / 0.073.
+// Above one round the big tile stays, also where the rounds model says otherwise: at 25 216 rows (the reference-shaped call of 128 frames)
+// out_proj is 297 tiles = "two rounds for 1.16 rounds of work" and 128-row tiles win (0.118 -> 0.106 ms), but c_proj on the same grid loses
+// (0.370 -> 0.388) and QKV / c_fc lose 13 - 17 %: this kernel runs at the chip's power limit (1.6 - 1.8 GHz, matrix pipe busy 0.6 - 0.7), the
+// CUs that still hold tiles speed up when the others run dry, and round 5 measured the fp32 kernel's remedy - a head of whole rounds plus a
+// tail launch of half tiles - at 0.191 ms for that out_proj.  No head + tail cut here.
 // Rows are independent and an element's K order only depends on its column tile: the result does not depend on the tile height.
-// `force`: 0 = by tile count, 1 = 256-row tiles, 2 = 128-row tiles (tests).
-bool x2_use_half_tiles(int M, int N, int cus, int force) {
+// `force`: 0 = by the rule, 1 = 256-row tiles, 2 = 128-row tiles (tests).
+bool x2_use_half_tiles(int M, int N, int cus, int force, int nsplit) {
   if (force == 1) return false;
   if (force == 2) return true;
   const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-  return tiles256 <= cus;
+  if (tiles256 > cus) return false;
+  const int per_xcd = std::max(1, cus / 8);
+  const int r256 = (x2_xcd_tiles(M, N, 256, nsplit) + per_xcd - 1) / per_xcd, r128 = (x2_xcd_tiles(M, N, 128, nsplit) + per_xcd - 1) / per_xcd;
+  return r128 * 0.575f < (float)r256;
 }
 
 template <int EPI, int RW = 4>
 int launch_x2_variant(const GemmArgs& a, hipStream_t stream, int force) {
-  return x2_use_half_tiles(a.M, a.N, device_cus(), force) ? launch_x2_tiles<EPI, RW, 128>(a, stream)
+  return x2_use_half_tiles(a.M, a.N, device_cus(), force, a.nsplit) ? launch_x2_tiles<EPI, RW, 128>(a, stream)
                                                           : launch_x2_tiles<EPI, RW, 256>(a, stream);
 }
 

@@ -84,9 +84,9 @@ typedef struct {
                                  fp32 path.  2: the same GEMMs on the fp16 matrix cores over TWO-plane operands ("x2" rows,
                                  fc_split2: x = h1 + 2^-11 h2 in fp16) with THREE products per fp32 product
                                  (fc_gemm_split2) - fp32 accuracy at ~2.7x the fp32-MFMA rate; so does the patch embedding
-                                 (patch sizes that are multiples of 8) and, in an fc_encode_text CALL of 4096 token rows or
-                                 more (54 captions of 77 tokens; text widths that are multiples of 256), the four block
-                                 GEMMs of the text tower - a smaller call cannot fill the chip with that kernel's tiles and
+                                 (patch sizes that are multiples of 8) and, in an fc_encode_text CALL of 2048 token rows or
+                                 more (27 captions of 77 tokens; text widths that are multiples of 256), the four block
+                                 GEMMs of the text tower - a smaller call is one tile's latency with that kernel and
                                  keeps the fp32 kernels: one arithmetic per call, rows independent of the rest of the call
                                  within either kind.  fp16 planes hold
                                  |x| <= 65504: a value beyond that (or an infinite / NaN value or weight) raises a device-side

@@ -341,7 +341,7 @@ def test_bench_describes_the_arithmetic_from_the_librarys_records():
     gemms = [{"kind": 0, "precision": 2, "epilogue": 10, "N": 3072, "K": 3 * 768}, {"kind": 0, "precision": 2, "epilogue": 3, "N": 768, "K": 3 * 768},
              {"kind": 0, "precision": 0, "epilogue": 1, "N": 2048, "K": 512}]          # (the text tower of a small call: fp32 kernels)
     assert bench.gemm_description(gemms, synth.VIT_B_16, 2, 3) == "the visual tower's block GEMMs, its patch embedding"
-    gemms[2] = {"kind": 0, "precision": 2, "epilogue": 10, "N": 2048, "K": 3 * 512}  # (a call of >= 4096 token rows)
+    gemms[2] = {"kind": 0, "precision": 2, "epilogue": 10, "N": 2048, "K": 3 * 512}  # (a call of >= 2048 token rows)
     assert bench.gemm_description(gemms, synth.VIT_B_16, 2, 3).endswith("its patch embedding, the text tower's block GEMMs")
     assert bench.gemm_description(gemms[2:], synth.VIT_B_16, 1, 6) == "no GEMM recorded"
     dtype = bench.SPLIT_MODES["fp32x3"][5].format(gemms=bench.gemm_description(gemms, synth.VIT_B_16, 2, 3),

@@ -270,7 +270,7 @@ def test_full_size_batches_by_invariance(vitb16_state_dict, clips, frames, n_tex
     ref_v = enc.encode_video(base_v)
     ref_t = enc.encode_text({"input_ids": base_t})
     if precision == "fp32x3":
-        # this mode picks the text tower's arithmetic per CALL (from 4096 token rows on: the three-product GEMMs; below, the fp32
+        # this mode picks the text tower's arithmetic per CALL (from 2048 token rows on: the three-product GEMMs; below, the fp32
         # kernels - tests/test_gpu_split2.py), so the captions "alone" are computed in a call of the big batch's kind: 8 x 8 of them
         ref_t = enc.encode_text({"input_ids": base_t.repeat(8, 1)})[:8]
     gen = torch.Generator().manual_seed(1)

@@ -60,6 +60,21 @@ def test_reference_shaped_call_replays_bitwise_from_a_hipgraph(vitb16_state_dict
     assert torch.isfinite(ev).all() and torch.isfinite(et).all()
 
 
+def test_plane_text_call_replays_bitwise_from_a_hipgraph(vitb16_state_dict):
+    """fp32x3 with 64 captions per call (4928 token rows): the text tower's block GEMMs run on the three-product kernel, and the output
+    scan + the range flag's copy to its pinned mirror at the end of `fc_encode_text` are captured with them."""
+    d = synth.VIT_B_16
+    enc = ClipVideoTextEncoder(build_clip(vitb16_state_dict, precision="fp32x3", device=DEV), num_frames=2)
+    video = torch.from_numpy(synth.make_video(64, 2, d, seed=4)).to(DEV)
+    ids = torch.from_numpy(synth.make_text(64, d, seed=4)).to(DEV)
+    ev, et, scores, ranks, fused = _capture_and_replay(enc, video, ids)
+    enc.model.check_range()
+    plain = ClipVideoTextEncoder(build_clip(vitb16_state_dict, precision="fp32", device=DEV), num_frames=2)
+    want = plain.encode_text({"input_ids": ids})
+    assert not torch.equal(et, want) and float((et - want).abs().max()) < 2e-6       # the plane arithmetic, at fp32 accuracy
+    assert torch.equal(ranks, fused) and torch.isfinite(ev).all()
+
+
 def test_graph_with_new_inputs_in_the_captured_buffers(tiny_state_dict):
     """A captured graph reads its inputs from the addresses it was captured with: new data copied INTO those tensors must come
     out as the eager result for that data (the usual serving pattern: static input buffers, one graph launch per batch)."""

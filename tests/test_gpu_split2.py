@@ -315,7 +315,7 @@ def test_towers_match_reference_fixtures(golden_dir, tag, dims, request):
         assert np.abs(img.cpu().numpy() - g[f"image_features_{ref}"]).max() < F32_TOL * scale, ref
     assert float((img - plain.encode_image(frames)).abs().max()) < 2e-6 * scale       # next to the fp32-MFMA path
     ids = torch.from_numpy(g["ids"]).to(DEV)
-    assert torch.equal(model.encode_text(ids), plain.encode_text(ids))                 # (a call below 4096 token rows: the fp32 kernels)
+    assert torch.equal(model.encode_text(ids), plain.encode_text(ids))                 # (a call below 2048 token rows: the fp32 kernels)
 
 
 def test_evaluate_goldens_in_three_product_mode(golden_dir, vitb16_state_dict):
@@ -543,21 +543,21 @@ def test_strict_range_makes_every_call_answer_for_itself(tiny_state_dict):
 
 
 def test_text_tower_joins_the_mode_for_large_calls(vitb16_state_dict):
-    """fc_encode_text in fp32x3: a call of >= 4096 token rows (54 captions of 77 tokens) runs the text blocks' four GEMMs on the
-    three-product kernel, a smaller call the fp32 kernels (too few 256-row tiles for 256 CUs).  One arithmetic per CALL: a small call has
+    """fc_encode_text in fp32x3: a call of >= 2048 token rows (27 captions of 77 tokens) runs the text blocks' four GEMMs on the
+    three-product kernel, a smaller call the fp32 kernels (a launch of the plane kernel is one tile's latency there).  One arithmetic per CALL: a small call has
     the fp32 path's bits, a large one its values at fp32 accuracy, and rows depend neither on the batch nor on the pass size."""
     from oracle import clip_oracle as O
     d = synth.VIT_B_16
     split = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV)
     plain = build_clip(vitb16_state_dict, precision="fp32", device=DEV)
     ids = torch.from_numpy(synth.make_text(300, d, seed=5)).to(DEV)
-    assert torch.equal(split.encode_text(ids[:53]), plain.encode_text(ids[:53]))        # 4081 rows: the fp32 kernels
+    assert torch.equal(split.encode_text(ids[:26]), plain.encode_text(ids[:26]))        # 2002 rows: the fp32 kernels
     big, ref = split.encode_text(ids), plain.encode_text(ids)
     split.check_range()
     scale = max(1.0, float(ref.abs().max()))
     assert float((big - ref).abs().max()) < 2e-6 * scale
     assert not torch.equal(big, ref)                                                     # (it IS the other arithmetic)
-    assert torch.equal(split.encode_text(ids[:54]), big[:54])                            # 4158 rows: same bits in any large batch
+    assert torch.equal(split.encode_text(ids[:27]), big[:27])                            # 2079 rows: same bits in any large batch
     passes = build_clip(vitb16_state_dict, precision="fp32x3", device=DEV, chunk_texts=128)
     assert torch.equal(passes.encode_text(ids), big)                                     # passes of 128, 128, 44 captions
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in O.to_torch(vitb16_state_dict).items()}

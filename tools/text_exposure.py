@@ -1,6 +1,6 @@
 """What the text tower costs the bench step (256 clips x 8 frames + 256 captions, ViT-B/16): the forward with the towers on two
 streams and on one, and each tower alone - fp32x3 and fp32.  Also encode_text alone at 32 / 54 / 128 captions (fp32x3 switches the
-text blocks to the three-product GEMMs from 4096 token rows per call on).
+text blocks to the three-product GEMMs from 2048 token rows per call on).
     python tools/text_exposure.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -26,10 +26,9 @@ for prec in ("fp32x3", "fp32"):
         enc.overlap_text = False
         serial = t(lambda: enc(video=video, text={"input_ids": ids}))
     print(f"{prec}: forward (two streams) {both:.1f} ms, one stream {serial:.1f} ms; encode_video alone {v:.1f} ms, encode_text alone {tx:.1f} ms -> the text tower costs {both - v:.1f} ms beside the visual tower ({serial - v:.1f} serial)", flush=True)
-for n in (32, 53, 54, 128, 256):
-    row = []
-    for prec in ("fp32x3", "fp32"):
-        m = build_clip(sd, precision=prec, device="cuda:0")
+models = {prec: build_clip(sd, precision=prec, device="cuda:0") for prec in ("fp32x3", "fp32")}
+for rnd in range(2):
+    for n in (8, 16, 26, 27, 28, 30, 32, 33, 36, 40, 48, 64, 128, 256):
         with torch.no_grad():
-            row.append(t(lambda: m.encode_text(ids[:n]), reps=10))
-    print(f"encode_text, {n:3d} captions: fp32x3 {row[0]:.2f} ms, fp32 {row[1]:.2f} ms", flush=True)
+            row = [t(lambda: models[prec].encode_text(ids[:n]), reps=10) for prec in ("fp32x3", "fp32")]
+        print(f"round {rnd}: encode_text, {n:3d} captions: fp32x3 {row[0]:.2f} ms, fp32 {row[1]:.2f} ms", flush=True)

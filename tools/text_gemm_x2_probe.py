@@ -22,7 +22,7 @@ def timed(fn, reps=20, rounds=5):
 
 
 g = torch.Generator(device="cuda").manual_seed(0)
-for captions in (256, 128, 64, 54, 32):
+for captions in (256, 128, 64, 54, 32, 24, 16, 8):
     M = captions * 77
     tot32 = tot2 = 0.0
     for name, N, K, epi32, epi2 in (("qkv", 1536, 512, ops.EPI_BIAS_T, ops.EPI_BIAS_F32), ("out_proj", 512, 512, ops.EPI_BIAS_T, ops.EPI_BIAS_F32),
