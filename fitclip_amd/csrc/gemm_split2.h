@@ -53,8 +53,9 @@ constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
 }
 
 // ABL (tools/x2k_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 3 = no epilogue; 6 = no loads, no waits, no
-// epilogue (MFMA + LDS reads only); 4 = the real kernel with s_memtime stamps around the hand-over wait, the hand-over barrier, the
-// K loop and the epilogue, summed per wave into g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).
+// epilogue (MFMA + LDS reads only); 7 = the real kernel with conflict-free (and WRONG) patch writes of the x2 epilogue; 4 = the real
+// kernel with s_memtime stamps around the hand-over wait, the hand-over barrier, the K loop and the epilogue, summed per wave into
+// g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).
 // RW: residual / positional-embedding rows requested RW patches (16 rows x 32 columns) ahead (EPI_RESID3_F32, EPI_PATCH_F32).
 // PF: activation fragments requested PF row tiles ahead (2: three register sets, 256-row tiles only)
 // PRIO (lab): 1 = waves 4..7 (the later-dispatched partner on every SIMD) at s_setprio 2 for the whole kernel; 2 = the two halves
@@ -89,6 +90,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X2 || EPI == EPI_RESID3_F32 || EPI == EPI_PATCH_F32, "epilogue");
   static_assert(LPW + NST < 64, "the counted wait behind the epilogue stores must fit the 6-bit vmcnt");
 
+  constexpr int ABLK = ABL == 7 ? 0 : ABL;   // (ABL 7 is the real kernel but for its patch-write addresses)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,8 +242,8 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
       static_for<NG>([&](auto U) {
         constexpr int u = decltype(U)::value;
         constexpr bool tail = u + 1 == NG;
-        if constexpr (ABL == 4 && u == 0 && !first) st_g0 = stamp();
-        if constexpr (ABL == 4 && u == NG / 2 && !first) {
+        if constexpr (ABLK == 4 && u == 0 && !first) st_g0 = stamp();
+        if constexpr (ABLK == 4 && u == NG / 2 && !first) {
           st_g4 = stamp();
           st_first += st_g4 - st_g0;       // groups 0 .. NG / 2 - 1 of this wave
         }
@@ -259,19 +261,19 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
             // have returned the stage may be refilled (with K-step kt + 2)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             unsigned long long s0 = 0, s1 = 0;
-            if constexpr (ABL == 4) s0 = stamp();
-            if constexpr (ABL == 4 && !first) st_half += s0 - st_g4;   // groups NG / 2 .. NG - 2 of this wave
-            if constexpr (ABL < 5) {
+            if constexpr (ABLK == 4) s0 = stamp();
+            if constexpr (ABLK == 4 && !first) st_half += s0 - st_g4;   // groups NG / 2 .. NG - 2 of this wave
+            if constexpr (ABLK < 5) {
               if (kt == 0 && prev_counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
             }
-            if constexpr (ABL == 4) s1 = stamp();
+            if constexpr (ABLK == 4) s1 = stamp();
             block_barrier();
-            if constexpr (ABL == 4) {
+            if constexpr (ABLK == 4) {
               const unsigned long long s2 = stamp();
               st_data += s1 - s0;
               st_bar += s2 - s1;
             }
-            if (ABL != 1 && ABL < 5) {
+            if (ABLK != 1 && ABLK < 5) {
               if (kt + 2 < nk) {
                 static_for<LPW>([&](auto I) {
                   if constexpr (x2_piece_slot(SPREAD, decltype(I)::value, LPA) < 0) stage_piece(par, kt + 2, I);
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
         if constexpr (tail) read_w(par ^ 1, 1, g2);
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gs[j], af[u % NAF][1], acc[u][j], 0, 0, 0);
-        if constexpr (SPREAD > 0 && ABL != 1 && ABL < 5 && !tail && !first) {
+        if constexpr (SPREAD > 0 && ABLK != 1 && ABLK < 5 && !tail && !first) {
           // K-step kt + 1 (or K-step 0 of the next tile) into the stage the previous hand-over released - UNCONDITIONALLY: behind
           // the last K-step of a workgroup's last tile the pieces fetch K-step 0 of that tile once more (valid addresses, a stage
           // nobody reads; drained before the kernel ends)
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
         }
       });
     };
-    if constexpr (ABL == 4) st_mark = stamp();
+    if constexpr (ABLK == 4) st_mark = stamp();
     kstep(0, std::integral_constant<int, 0>{}, std::true_type{});
     kstep(1, std::integral_constant<int, 1>{}, std::false_type{});
     for (int kt = 2; kt < nk; kt += 2) {
@@ -343,14 +345,14 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
       kstep(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
     // g1 / g2 / af[0] now hold the first fragments of the next tile
-    if constexpr (ABL == 4) {
+    if constexpr (ABLK == 4) {
       const unsigned long long now = stamp();
       st_k += now - st_mark;
       st_mark = now;
     }
 
     const bool interior = cm0 + BM <= g.M && cn0 + BN <= g.N;
-    if constexpr (ABL == 3 || ABL >= 6) {
+    if constexpr (ABLK == 3 || ABLK >= 6) {
       float keep = 0.f;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -455,7 +457,10 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
           // pt + 1 are computed between the writes and the reads of patch pt.
           const size_t ldc_b = (size_t)g.ldc * 2;
           char* cbase = reinterpret_cast<char*>(g.C) + (size_t)(cm0 + wm * TM + rrow) * ldc_b + rch * 16;
-          char* wr = stg + c * 128 + (q & 1) * 8;
+          // (the 16 lanes of a ds_write_b64 group hold ONE 8-byte half of 16 rows, and rows c, c ^ 9 share a chunk: a two-way conflict,
+          // 16 LDS cycles per patch.  ABL 7, lab only: the half also taken from the row's parity - conflict-free, WRONG data - sizes
+          // what a conflict-free layout could gain: docs/rounds/round6.md)
+          char* wr = stg + c * 128 + ((q & 1) ^ (ABL == 7 ? (c & 1) : 0)) * 8;
           const int qh = q >> 1;
           // range test on the PLANES: h1 = fp16(v) is an infinity exactly when v does not fit fp16 (|v| >= 65520) and a NaN when v
           // is one, and either turns `bad` into a NaN for good (x * 0 + bad, two packed instructions per four values; a running
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
         }
       };
       if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
-      if constexpr (ABL == 4) {
+      if constexpr (ABLK == 4) {
         st_epi += stamp() - st_mark;
         ++st_tiles;
       }
@@ -513,7 +518,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
     ++it;
     t = tnext;
   }
-  if constexpr (ABL == 4) {
+  if constexpr (ABLK == 4) {
     if (lane == 0 && g.aux) {
       unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.aux)) + ((size_t)blockIdx.x * NW + wave) * 8;
       d[0] = st_data; d[1] = st_bar; d[2] = st_k; d[3] = st_epi; d[4] = st_tiles; d[5] = (unsigned long long)nk; d[6] = st_first; d[7] = st_half;

@@ -19,8 +19,12 @@ int launch_variant(const GemmArgs& a, hipStream_t stream) {
   auto kern = gemm_split3_kernel<EPI, 0, 1, RW, NTA, RR>;
   if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess)
     return fail(FC_ELAUNCH, "gemm_split3: cannot raise dynamic LDS to %d bytes", lds);
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, device_cus())), dim3(512), lds, stream, a);
+  // as many workgroups per XCD as its BUSIEST XCD has tiles (the schedule gives every XCD a contiguous range of M-panels: with
+  // min(tiles, CUs) workgroups a launch below one round left that XCD with a second one - gemm_split2.hip: x2_xcd_tiles)
+  const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+  const int ngrp = (!RR && a.nsplit > 1 && 8 % a.nsplit == 0 && tilesN % a.nsplit == 0) ? a.nsplit : 1;
+  const int xcd_tiles = RR ? (tilesM * tilesN + 7) / 8 : ((tilesM + 8 / ngrp - 1) / (8 / ngrp)) * (tilesN / ngrp);
+  hipLaunchKernelGGL(kern, dim3(std::min(8 * xcd_tiles, device_cus())), dim3(512), lds, stream, a);
   FC_CHECK_LAUNCH("gemm_split3");
   return FC_OK;
 }

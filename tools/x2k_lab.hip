@@ -172,6 +172,7 @@ int main(int argc, char** argv) {
             {"m32 ABL1 no-loads", launch_m32<EPI_GELU_X2, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_GELU_X2, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_GELU_X2, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_GELU_X2, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_GELU_X2, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_GELU_X2, 6, 3>, ns},
+            {"k32 ABL7 conflict-free patch writes", launch_k32<EPI_GELU_X2, 7, 5>, ns},
             {"k32 ABL4 stamps", launch_k32<EPI_GELU_X2, 4, 5>, ns}};
     } else if (sh.epi == 2) {
       vs = {{"m32 shipped", launch_m32<EPI_RESID3_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_RESID3_F32, 0, 3>, ns},
