@@ -1005,7 +1005,7 @@ int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float
   a.A = A2; a.W = W2; a.bias = bias; a.C = C; a.aux = nullptr; a.alpha = 1.f; a.wscale = scale2; a.sat_flag = sat_flag;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc;
   if (!A2 || !W2 || !C || !scale2) return fail(FC_EINVAL, "fc_gemm_split2: null operand");
-  if (cut < 0 || cut > 2) return fail(FC_EINVAL, "fc_gemm_split2: cut %d", cut);
+  if (cut < 0 || cut > 3) return fail(FC_EINVAL, "fc_gemm_split2: cut %d", cut);
   return launch_gemm_split2(epilogue, a, st, cut);
 }
 

@@ -176,7 +176,7 @@ int launch_split3_rows(const float* in, long ld_in, void* out, long ld_out, long
 // split-fp32 GEMM over two-plane fp16 operands (gemm_split2.h).  a.K counts fp32 columns; a.lda / a.ldw count fp16 positions of
 // the x2 rows (>= 2 K); a.ldc counts floats (EPI_BIAS_F32, EPI_RESID3_F32) or fp16 positions of the x2 output rows
 // (EPI_GELU_X2, >= 2 N); a.wscale is required
-// force_cut: 0 = tile height by tile count (gemm_split2.hip: x2_use_half_tiles), 1 = 256-row tiles, 2 = 128-row tiles (tests)
+// force_cut: 0 = tile height by the rounds of the busiest XCD (gemm_split2.hip: x2_tile_height), 1 = 256-row, 2 = 128-row, 3 = 192-row tiles (tests)
 int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int force_cut = 0);
 bool gemm_split2_ok(const GemmArgs& a);
 // x2 image [rows, 2 K fp16] of fp32 activation rows [rows, K] (scaled residual plane; sat_flag as in GemmArgs)

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   constexpr int OFF_W = 2 * STG_A;
   constexpr int STAGE = STG_A + STG_W;             // bytes per stage: 65536 (49152)
   constexpr int LPA = BM / 8 / NW, LPB = BN / 8 / NW, LPW = LPA + LPB;  // LDS-DMA pieces per wave and stage: 4 (2) + 4
-  static_assert(BM == 256 || BM == 128, "tile height");
+  static_assert(BM == 256 || BM == 192 || BM == 128, "tile height");
   static_assert(FN == 4 && NG % 2 == 0, "wave tile");
   static_assert(PF == 1 || (PF == 2 && NG == 8), "prefetch distance");
   constexpr int NAF = PF + 1;                      // activation fragment sets: row tile i lives in set i % NAF

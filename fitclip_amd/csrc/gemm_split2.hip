@@ -37,34 +37,45 @@ int launch_x2_tiles(const GemmArgs& a, hipStream_t stream) {
   return FC_OK;
 }
 
-// Tile height.  The kernel is persistent over 256 x 256 tiles; a launch with fewer such tiles than compute units leaves CUs idle, and
-// 128-row tiles (half the MFMAs per staged weight tile: ~0.87 of the big tile's efficiency) then double the number of busy CUs.  Below
-// one round of big tiles the choice is by rounds of the busiest XCD (cus / 8 workgroups each): one round of half tiles beats one round of
-// big tiles, one round of big tiles beats two rounds of half tiles (2 x 0.5 / 0.87).  tools/x2_cut_probe.py on the balanced grid
-// (profiles/r06_x2_cut_probe.log; ms per launch, 256-row / 128-row tiles): a 32-frame call (6304 rows) QKV 0.096 / 0.066, out_proj 0.050 /
-// 0.035, c_proj 0.151 / 0.105; 12 608 rows out_proj 0.055 / 0.070, c_proj 0.162 / 0.219; the text tower at 256 captions (19 712 rows x
-// 768) out_proj 0.068 / 0.073.
-// Above one round the big tile stays, also where the rounds model says otherwise: at 25 216 rows (the reference-shaped call of 128 frames)
-// out_proj is 297 tiles = "two rounds for 1.16 rounds of work" and 128-row tiles win (0.118 -> 0.106 ms), but c_proj on the same grid loses
-// (0.370 -> 0.388) and QKV / c_fc lose 13 - 17 %: this kernel runs at the chip's power limit (1.6 - 1.8 GHz, matrix pipe busy 0.6 - 0.7), the
-// CUs that still hold tiles speed up when the others run dry, and round 5 measured the fp32 kernel's remedy - a head of whole rounds plus a
-// tail launch of half tiles - at 0.191 ms for that out_proj.  No head + tail cut here.
+// Tile height: 256, 192 or 128 rows (wave tiles of 128 / 96 / 64 x 64).  The kernel is persistent; what a launch costs is the number of
+// ROUNDS of its busiest XCD (cus / 8 workgroups each, x2_xcd_tiles) times the height of a tile, over the efficiency of that height (fewer
+// MFMAs per staged weight tile: 0.93 for 192 rows, 0.83 for 128 - fitted below).  The big tile stays unless another height is at least 7 %
+// cheaper by that count.  tools/x2_cut_probe.py (profiles/r06_x2_cut_probe.log; ms per launch at 256 / 192 / 128 rows; the model picks the
+// measured best in every row, its ties included):
+//   25 216 rows (the reference-shaped call of 128 frames): out_proj 0.119 / 0.097 / 0.108 (297 big tiles = two rounds for 1.16 rounds of
+//     work), c_proj 0.373 / 0.320 / 0.398, QKV 0.215 / 0.211 / 0.249, c_fc 0.293 / 0.306 / 0.322;
+//   12 608 rows: out_proj 0.056 / 0.049 / 0.071, c_proj 0.166 / 0.145 / 0.222, QKV 0.116 / 0.122 / 0.127;
+//   6304 rows (a 32-frame call): QKV 0.098 / 0.079 / 0.067, out_proj 0.050 / 0.041 / 0.035, c_fc 0.104 / 0.084 / 0.096, c_proj 0.152 / 0.125 / 0.105;
+//   the text tower at 256 captions (19 712 rows, width 512): out_proj 0.045 / 0.040 / 0.052, c_proj 0.116 / 0.103 / 0.154, QKV 0.083 / 0.089 / 0.092;
+//   50 432 rows and more: the big tile (403 456 rows: c_fc 4.57 / 4.71 / 5.33).
+// (Round 5 had measured the fp32 kernel's remedy for partial rounds - a head launch of whole rounds plus a tail launch of lower tiles - as
+// slower than either: at the power limit a second launch only adds its fill and drain.)
 // Rows are independent and an element's K order only depends on its column tile: the result does not depend on the tile height.
-// `force`: 0 = by the rule, 1 = 256-row tiles, 2 = 128-row tiles (tests).
-bool x2_use_half_tiles(int M, int N, int cus, int force, int nsplit) {
-  if (force == 1) return false;
-  if (force == 2) return true;
-  const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-  if (tiles256 > cus) return false;
+// `force`: 0 = by this rule, 1 = 256-row tiles, 2 = 128-row tiles, 3 = 192-row tiles (tests, tools/x2_cut_probe.py).
+int x2_tile_height(int M, int N, int cus, int force, int nsplit) {
+  if (force == 1) return 256;
+  if (force == 2) return 128;
+  if (force == 3) return 192;
   const int per_xcd = std::max(1, cus / 8);
-  const int r256 = (x2_xcd_tiles(M, N, 256, nsplit) + per_xcd - 1) / per_xcd, r128 = (x2_xcd_tiles(M, N, 128, nsplit) + per_xcd - 1) / per_xcd;
-  return r128 * 0.575f < (float)r256;
+  auto cost = [&](int bmt, float eff) {
+    const int rounds = (x2_xcd_tiles(M, N, bmt, nsplit) + per_xcd - 1) / per_xcd;
+    return (float)rounds * ((float)bmt / 256.f) / eff;
+  };
+  const float c192 = cost(192, 0.93f), c128 = cost(128, 0.83f);
+  int best = 256;
+  float cb = 0.93f * cost(256, 1.f);
+  if (c192 < cb) best = 192, cb = c192;
+  if (c128 < cb) best = 128;
+  return best;
 }
 
 template <int EPI, int RW = 4>
 int launch_x2_variant(const GemmArgs& a, hipStream_t stream, int force) {
-  return x2_use_half_tiles(a.M, a.N, device_cus(), force, a.nsplit) ? launch_x2_tiles<EPI, RW, 128>(a, stream)
-                                                          : launch_x2_tiles<EPI, RW, 256>(a, stream);
+  switch (x2_tile_height(a.M, a.N, device_cus(), force, a.nsplit)) {
+    case 128: return launch_x2_tiles<EPI, RW, 128>(a, stream);
+    case 192: return launch_x2_tiles<EPI, RW, 192>(a, stream);
+    default: return launch_x2_tiles<EPI, RW, 256>(a, stream);
+  }
 }
 
 // fp32 rows -> x2 rows: thread per (row, line of 32 columns, quarter): 8 values -> 16 bytes of either plane; the four threads of a

@@ -234,7 +234,7 @@ def gemm_split2(a2: torch.Tensor, w2: torch.Tensor, scale: torch.Tensor, bias: t
     """epilogue(A @ W^T) for x2 operands a2 [M, 2 K] (`split2`, LayerNorm / attention x2 outputs, a previous EPI_GELU_X2 GEMM) and
     (w2 [N, 2 K], scale) from `split2_weight`: three fp16 MFMA products per fp32 product, fp32 accumulate (fc_gemm_split2).
     EPI_BIAS_F32 -> float32 [M, N]; EPI_GELU_X2 -> x2 rows [M, 2 N] of QuickGELU(A @ W^T + bias); EPI_RESID3_F32: `out`
-    (float32 [M, N]) += A @ W^T + bias, in place (the other two write into `out` when one is given).  `cut` (tests): tile height - 0 = by tile count, 1 = 256 rows, 2 = 128 rows; the
+    (float32 [M, N]) += A @ W^T + bias, in place (the other two write into `out` when one is given).  `cut` (tests): tile height - 0 = the launcher's choice, 1 = 256 rows, 2 = 128 rows, 3 = 192 rows; the
     result does not depend on it."""
     _dev(a2, "a2", torch.float16), _dev(w2, "w2", torch.float16), _dev(bias, "bias", torch.float32), _dev(scale, "scale", torch.float32)
     if a2.dim() != 2 or w2.dim() != 2 or a2.shape[1] != w2.shape[1] or a2.shape[1] % 64:

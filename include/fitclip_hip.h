@@ -252,8 +252,8 @@ FC_API int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld
  * on v_mfma_f32_16x16x32_f16, accumulated in fp32 - the reference's fp32 `F.linear` (slip.py:366-390) to 2^-22 per product.
  * epilogue 6: C fp32 [M, N] = acc + bias; 8: C fp32 += acc + bias in place; 10: C x2 rows [M, 2 N fp16] =
  * planes(QuickGELU(acc + bias)) (sat_flag as in fc_split2).  K % 64 == 0, K >= 128, N % 32 == 0; operands below 4 GiB.
- * `cut`: the tile height of the persistent kernel - 0: 256 rows, or 128 when there are fewer 256-row tiles than compute units
- * (small batches), 1: 256 rows, 2: 128 rows (tests).  Results do not depend on it. */
+ * `cut`: the tile height of the persistent kernel - 0: 256, 192 or 128 rows, whichever costs the busiest XCD the fewest rounds x rows
+ * (small and mid-size batches leave the big tile), 1: 256 rows, 2: 128 rows, 3: 192 rows (tests).  Results do not depend on it. */
 FC_API int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float* scale2, const float* bias, void* C,
                    int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, int32_t cut,
                    fc_stream stream);

@@ -138,15 +138,15 @@ def test_residual_epilogue_is_the_bias_epilogue_plus_the_stream(M, N, K):
 @pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 2304, 768), (25216, 768, 3072), (7000, 3072, 768), (130, 768, 768),
                                    (6425, 1024, 1024), (6425, 4096, 1024), (6425, 1024, 4096)])   # 25 frames of ViT-L/14
 def test_tile_height_is_bit_invisible(M, N, K, epi):
-    """Launches with fewer 256-row tiles than CUs run on 128-row tiles (twice the busy CUs): an element sees the same K order and
-    the same product chain whatever tile holds it, so the automatic choice, 256-row and 128-row tiles give the same bits."""
+    """The launcher picks 256-, 192- or 128-row tiles by the rounds of the busiest XCD: an element sees the same K order and the same
+    product chain whatever tile holds it, so the automatic choice and the three forced heights give the same bits."""
     g = torch.Generator(device=DEV).manual_seed(M + N)
     a2 = ops.split2(torch.randn(M, K, device=DEV, generator=g))
     w2, sc = ops.split2_weight(torch.randn(N, K, device=DEV, generator=g) / K ** 0.5)
     bias = torch.randn(N, device=DEV, generator=g)
     x = torch.randn(M, N, device=DEV, generator=g)
     outs = []
-    for cut in (1, 0, 2):
+    for cut in (1, 0, 2, 3):
         if epi == "resid":
             o = x.clone()
             ops.gemm_split2(a2, w2, sc, bias, ops.EPI_RESID3_F32, out=o, cut=cut)
@@ -177,7 +177,7 @@ def test_ragged_column_tiles(M, N, K):
     h2 = ops.gemm_split2(a2, w2, sc, bias, ops.EPI_GELU_X2)
     want = ref * torch.sigmoid(1.702 * ref)
     assert h2.shape == (M, 2 * N) and float((_value(h2) - want).abs().max() / want.abs().max()) < 1.5e-6   # (the GEMM's own error, through the GELU)
-    for cut in (1, 2):
+    for cut in (1, 2, 3):
         assert torch.equal(ops.gemm_split2(a2, w2, sc, bias, cut=cut), y)
 
 

@@ -28,7 +28,7 @@ def gemm_case(rng, i):
     N = 32 * int(rng.integers(1, 97))                      # 32 .. 3072
     M = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 5000)), int(rng.integers(5000, 70000))]))
     epi = str(rng.choice(["bias", "resid", "gelu"]))
-    cut = int(rng.integers(0, 3))
+    cut = int(rng.integers(0, 4))
     g = torch.Generator(device=DEV).manual_seed(1000 + i)
     a = torch.randn(M, K, device=DEV, generator=g) * float(10.0 ** rng.uniform(-2, 1.5))
     w = torch.randn(N, K, device=DEV, generator=g) * float(10.0 ** rng.uniform(-3, 0.5)) / K ** 0.5
