@@ -47,8 +47,9 @@ The same JSON line carries
     device path over the whole batch, and on the CPU sample the device path ("gpu"), the oracle ("ref") and "delta".
   * "cpu_baseline": the CPU oracle (oracle/clip_oracle.py, kind "port") timed on this host's cores over a bounded
     sample of the same workload (rank 0, N = 1 only), next to the parity of the GPU embeddings on that sample.
-  * `fp32_split_mode`: the same step with `precision="fp32x3"` - the visual tower's block GEMMs on the fp16 matrix cores
-    over two-plane split-fp32 operands, three fp16 products per fp32 product (fc_config.split_gemm = 2) - with its parity
+  * `fp32_split_mode`: the same step with `precision="fp32x3"` - the towers' block GEMMs, the patch embedding and the visual
+    attention on the fp16 matrix cores over two-plane split-fp32 operands, three fp16 products per fp32 product
+    (fc_config.split_gemm = 2; its `dtype` names what the step's own records show) - with its parity
     against the fp32 path and the oracle.  A labelled secondary mode like `bf16_mode`; never `value`.  `--split6` adds
     `fp32_split6_mode` (precision "fp32x6": three bf16 planes, six bf16 products - the split mode of rounds 2-4).
   * `kd_training_step` (N = 1 only, after the timed region): the distillation training step at one
@@ -474,7 +475,7 @@ def gemm_description(records, dims, prec_code: int, nprod: int) -> str:
 
 
 def run_split_mode(sd, video, text, args, shards, device, backend, precision="fp32x3"):
-    """Secondary legs `fp32_split_mode` (precision "fp32x3": the visual tower's block GEMMs on the fp16 matrix cores over two-plane
+    """Secondary legs `fp32_split_mode` (precision "fp32x3": the block GEMMs on the fp16 matrix cores over two-plane
     operands, THREE fp16 products per fp32 product formed from registers, csrc/gemm_split2.h) and `fp32_split6_mode` (`--split6`;
     precision "fp32x6": three bf16 planes, six bf16 products, csrc/gemm_split3.h) - fp32 accuracy from the pipes that are 16x
     faster than the fp32-input one.  Timed like the headline; the per-kernel figures come from one instrumented extra step."""
