@@ -53,7 +53,8 @@ constexpr int x2_piece_slot(int spread, int idx, int lpa = 4) {
 }
 
 // ABL (tools/x2k_lab only): 0 = real kernel; 1 = no global loads inside the K loop; 3 = no epilogue; 6 = no loads, no waits, no
-// epilogue (MFMA + LDS reads only); 7 = the real kernel with conflict-free (and WRONG) patch writes of the x2 epilogue; 4 = the real
+// epilogue (MFMA + LDS reads only); 7 = the real kernel with conflict-free (and WRONG) patch writes of the x2 epilogue; 8 = two products per line (g1 h1 + g2 h2: the issue
+// pattern of a plain 16-bit GEMM over 64-column lines - sizes what this kernel's structure would give the bf16 mode); 4 = the real
 // kernel with s_memtime stamps around the hand-over wait, the hand-over barrier, the K loop and the epilogue, summed per wave into
 // g.aux (8 x uint64 per wave; a diagnostic build: the stamps cost time themselves).
 // RW: residual / positional-embedding rows requested RW patches (16 rows x 32 columns) ahead (EPI_RESID3_F32, EPI_PATCH_F32).
@@ -90,7 +91,9 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   static_assert(EPI == EPI_BIAS_F32 || EPI == EPI_GELU_X2 || EPI == EPI_RESID3_F32 || EPI == EPI_PATCH_F32, "epilogue");
   static_assert(LPW + NST < 64, "the counted wait behind the epilogue stores must fit the 6-bit vmcnt");
 
-  constexpr int ABLK = ABL == 7 ? 0 : ABL;   // (ABL 7 is the real kernel but for its patch-write addresses)
+  constexpr int ABLK = ABL == 7 || ABL == 8 ? 0 : ABL;   // (ABL 7 / 8 are the real kernel but for the patch-write addresses / the products)
+  constexpr bool kTwo = ABL == 8;            // lab: TWO products per line, g1 h1 + g2 h2 - what a plain 16-bit GEMM over 64-column lines issues
+  constexpr int NPROD = kTwo ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,18 +301,22 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
         if constexpr (u == 0) {
           // the third weight operand of this K-step: 2^-11 g1 (exact for g1 >= 2^-3; below, its error is 2^-25 absolute on a term
           // that is 2^-11 of the product)
+          if constexpr (!kTwo) {
 #pragma unroll
-          for (int j = 0; j < FN; ++j) gs[j] = g1[j] * static_cast<_Float16>(1.f / X2_RESID_SCALE);
+            for (int j = 0; j < FN; ++j) gs[j] = g1[j] * static_cast<_Float16>(1.f / X2_RESID_SCALE);
+          }
         }
         // products in issue order: g1 h1, g2 h1, (2^-11 g1) h2 - consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1[j], af[u % NAF][0], acc[u][j], 0, 0, 0);
         if constexpr (tail) read_w(par ^ 1, 0, g1);   // plane by plane: the next K-step's weights take the registers just released
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g2[j], af[u % NAF][0], acc[u][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g2[j], af[u % NAF][kTwo ? 1 : 0], acc[u][j], 0, 0, 0);
         if constexpr (tail) read_w(par ^ 1, 1, g2);
+        if constexpr (!kTwo) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gs[j], af[u % NAF][1], acc[u][j], 0, 0, 0);
+          for (int j = 0; j < FN; ++j) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gs[j], af[u % NAF][1], acc[u][j], 0, 0, 0);
+        }
         if constexpr (SPREAD > 0 && ABLK != 1 && ABLK < 5 && !tail && !first) {
           // K-step kt + 1 (or K-step 0 of the next tile) into the stage the previous hand-over released - UNCONDITIONALLY: behind
           // the last K-step of a workgroup's last tile the pieces fetch K-step 0 of that tile once more (valid addresses, a stage
@@ -326,14 +333,14 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
           constexpr int kReads = PF == 1 ? 2 : (u == 0 ? 4 : u + 2 < NG ? 2 : 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if constexpr (kReads > 0) __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 3 * FN - 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NPROD * FN - 1, 0);
         } else {
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, FN, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, FN, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+          if constexpr (!kTwo) __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
         }
       });
     };

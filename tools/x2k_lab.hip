@@ -177,6 +177,7 @@ int main(int argc, char** argv) {
     } else if (sh.epi == 2) {
       vs = {{"m32 shipped", launch_m32<EPI_RESID3_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_RESID3_F32, 0, 3>, ns},
             {"k32 spread5", launch_k32<EPI_RESID3_F32, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_RESID3_F32, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_RESID3_F32, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_RESID3_F32, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_RESID3_F32, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_RESID3_F32, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_RESID3_F32, 0, 5, 4, 2>, ns}, {"k32 ABL4 stamps pf2", launch_k32<EPI_RESID3_F32, 4, 5, 4, 2>, ns},
+            {"k32 ABL8 two products per line", launch_k32<EPI_RESID3_F32, 8, 5>, ns},
             {"k32 spread5 rw2", launch_k32<EPI_RESID3_F32, 0, 5, 2>, ns}, {"k32 spread5 rw6", launch_k32<EPI_RESID3_F32, 0, 5, 6>, ns}, {"k32 spread5 rw8", launch_k32<EPI_RESID3_F32, 0, 5, 8>, ns}, {"k32 spread5 rw16", launch_k32<EPI_RESID3_F32, 0, 5, 16>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_RESID3_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_RESID3_F32, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_RESID3_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_RESID3_F32, 3, 3>, ns},
@@ -185,7 +186,7 @@ int main(int argc, char** argv) {
     } else {
       vs = {{"m32 shipped", launch_m32<EPI_BIAS_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_BIAS_F32, 0, 3>, ns},
             {"k32 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_BIAS_F32, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 2>, ns},
-            {"k32 ABL4 stamps pf2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 2>, ns},
+            {"k32 ABL4 stamps pf2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 2>, ns}, {"k32 ABL8 two products per line", launch_k32<EPI_BIAS_F32, 8, 5>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_BIAS_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_BIAS_F32, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_BIAS_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_BIAS_F32, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_BIAS_F32, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_BIAS_F32, 6, 3>, ns},
