@@ -74,6 +74,7 @@ SIGNATURES = {
     "fc_wise": (_i32, [_vp, _vp, _f64, _vp, _sz, _vp]),
     "fc_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fc_gemm_plan": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "fc_gemm_split2_plan": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "fc_layernorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "fc_add_layernorm": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fc_attention": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

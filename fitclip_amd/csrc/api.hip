@@ -474,7 +474,9 @@ int gemm_x2(fc_handle* h, int epi, const void* A2, const void* W2, const float* 
   a.M = M; a.N = N; a.K = K; a.lda = (int)x2_row_elems(K); a.ldw = a.lda; a.ldc = ldc; a.P = P;
   GemmArgs rec = a;  // the profiling record counts the fp16 work: three products per fp32 product (precision code 2 = fp16 pipe)
   rec.K = 3 * K;
-  ProfScope ps(h, st, 2, epi, 3, rec);
+  int rows = 0, wgs = 0;
+  gemm_split2_plan(M, N, 0, &rows, &wgs);   // (the record's `tile`: the tile height of this launch)
+  ProfScope ps(h, st, 2, epi, rows, rec);
   return launch_gemm_split2(epi, a, st);
 }
 
@@ -943,6 +945,14 @@ int fc_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t* head_panels, int32_t*
   gemm_tail_plan(M, N, K, &hp, &ht);
   *head_panels = hp;
   *tail_units = ht;
+  return FC_OK;
+}
+int fc_gemm_split2_plan(int32_t M, int32_t N, int32_t compute_units, int32_t* tile_rows, int32_t* workgroups) {
+  if (M <= 0 || N <= 0 || !tile_rows || !workgroups) return fail(FC_EINVAL, "fc_gemm_split2_plan: bad argument");
+  int rows = 0, wgs = 0;
+  gemm_split2_plan(M, N, compute_units, &rows, &wgs);
+  *tile_rows = rows;
+  *workgroups = wgs;
   return FC_OK;
 }
 int fc_layernorm(const float* x, int64_t xs, const int32_t* gather, const float* g, const float* b, void* y,

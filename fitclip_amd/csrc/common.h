@@ -178,6 +178,7 @@ int launch_split3_rows(const float* in, long ld_in, void* out, long ld_out, long
 // (EPI_GELU_X2, >= 2 N); a.wscale is required
 // force_cut: 0 = tile height by the rounds of the busiest XCD (gemm_split2.hip: x2_tile_height), 1 = 256-row, 2 = 128-row, 3 = 192-row tiles (tests)
 int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int force_cut = 0);
+void gemm_split2_plan(int M, int N, int cus, int* tile_rows, int* workgroups);   // (host arithmetic only: the launch of an [M, N] problem)
 bool gemm_split2_ok(const GemmArgs& a);
 // x2 image [rows, 2 K fp16] of fp32 activation rows [rows, K] (scaled residual plane; sat_flag as in GemmArgs)
 int launch_split2_rows(const float* in, long ld_in, void* out, long ld_out, long rows, int K, int* sat_flag, hipStream_t stream);

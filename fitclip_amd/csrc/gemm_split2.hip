@@ -213,6 +213,19 @@ bool gemm_split2_ok(const GemmArgs& a) {
          ((uintptr_t)a.bias & 15) == 0 && (size_t)256 * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);
 }
 
+// the N range of a wide problem is split over XCD groups (gemm_split2.h: nsplit): the weights of a group's column tiles stay in its L2
+static int x2_auto_nsplit(int N) { return (N / 256) % 4 == 0 && N / 256 >= 8 && N % 256 == 0 ? 4 : 0; }
+
+// What launch_gemm_split2 will do with an [M, N] problem on `cus` compute units (<= 0: the current device): the tile height it picks and
+// the number of workgroups it launches.  Pure host arithmetic (tests/test_launch_plan.py pins it without a GPU).
+void gemm_split2_plan(int M, int N, int cus, int* tile_rows, int* workgroups) {
+  if (cus <= 0) cus = device_cus();
+  const int nsplit = x2_auto_nsplit(N);
+  const int rows = x2_tile_height(M, N, cus, 0, nsplit);
+  *tile_rows = rows;
+  *workgroups = std::min(8 * x2_xcd_tiles(M, N, rows, nsplit), cus);
+}
+
 int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int force_cut) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail(FC_EINVAL, "gemm_split2: empty problem %dx%dx%d", a.M, a.N, a.K);
   if (a.K % 64 || a.K < 128) return fail(FC_EINVAL, "gemm_split2: K=%d must be a multiple of 64, at least 128", a.K);
@@ -228,7 +241,7 @@ int launch_gemm_split2(int epilogue, const GemmArgs& a, hipStream_t stream, int 
   if ((size_t)256 * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32))
     return fail(FC_EINVAL, "gemm_split2: the weight (or a 256-row tile of the activations) exceeds the 4 GiB of the kernel's 32-bit row offsets");
   GemmArgs b = a;
-  if (b.nsplit == 0 && (b.N / 256) % 4 == 0 && b.N / 256 >= 8 && b.N % 256 == 0) b.nsplit = 4;
+  if (b.nsplit == 0) b.nsplit = x2_auto_nsplit(b.N);
   switch (epilogue) {
     case EPI_BIAS_F32:
       if (a.ldc % 4 || a.ldc < a.N) return fail(FC_EINVAL, "gemm_split2: ldc=%d", a.ldc);

@@ -79,6 +79,15 @@ def gemm_plan(M: int, N: int, K: int) -> "tuple[int, int]":
     return hp.value, ht.value
 
 
+def gemm_split2_plan(M: int, N: int, compute_units: int = 0) -> "tuple[int, int]":
+    """(tile_rows, workgroups): the tile height (256 / 192 / 128) `gemm_split2` picks for an [M, N] problem and the workgroups it launches
+    on `compute_units` CUs (0: the current device).  Host arithmetic: needs no GPU when `compute_units` is given.  fc_gemm_split2_plan."""
+    import ctypes as C
+    rows, wgs = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.load().fc_gemm_split2_plan(M, N, compute_units, C.byref(rows), C.byref(wgs)), "fc_gemm_split2_plan")
+    return rows.value, wgs.value
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype = torch.float32,
               gather: Optional[torch.Tensor] = None, row_stride: Optional[int] = None, rows: Optional[int] = None
               ) -> torch.Tensor:

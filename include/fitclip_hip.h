@@ -257,6 +257,10 @@ FC_API int fc_split2_weight(const float* w, int64_t ld_in, void* out, int64_t ld
 FC_API int fc_gemm_split2(int32_t epilogue, const void* A2, const void* W2, const float* scale2, const float* bias, void* C,
                    int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t* sat_flag, int32_t cut,
                    fc_stream stream);
+/* What fc_gemm_split2 (cut 0) does with an [M, N] problem on `compute_units` CUs (<= 0: the current device): the tile height it
+ * picks (256, 192 or 128 rows) and the workgroups it launches - 8 x the tiles of the busiest XCD under the kernel's schedule, at most
+ * one per CU.  Host arithmetic only: callable without a GPU when compute_units is given. */
+FC_API int fc_gemm_split2_plan(int32_t M, int32_t N, int32_t compute_units, int32_t* tile_rows, int32_t* workgroups);
 
 /* ---- training: the KD fine-tuning step of the student -------------------------------------------
  * Replaces autograd + torch.optim.AdamW for `TeacherStudentLightningModule.training_step / training_step_end /
@@ -351,7 +355,8 @@ typedef struct {
   int32_t precision; /* fc_precision */
   int32_t epilogue;  /* gemm: the epilogue id; attention: the arithmetic of the kernel that ran, as fc_attention's precision code (0 fp32
                         MFMA, 1 bf16, 3 fp32 with x3 rows out, 4 / 5 six bf16 products, 6 three fp16 products) */
-  int32_t tile;      /* gemm: the tile / row cut chosen; attention: 1 when a split pass over the fp32 output followed */
+  int32_t tile;      /* gemm: the tile / row cut chosen (the three-product GEMM: its tile height, 256 / 192 / 128 rows); attention: 1 when
+                        a split pass over the fp32 output followed */
   int32_t M, N, K;
   float ms;          /* elapsed between the two events; valid after the stream has been synchronised */
 } fc_prof_record;
