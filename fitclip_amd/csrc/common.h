@@ -154,8 +154,7 @@ struct GemmArgs {
   // k = (channel, py, px) of the im2col matrix are gathered by the LDS-DMA loader itself (no im2col pass in HBM).
   int gR, gP;
   int hp;             // pipelined kernel with a tail of lower tiles (gemm_kernel.h, HT > 0): 256-row panels of the head
-  int order;          // fp32 pipelined kernel: how the head tiles are dealt - 0 / 2 = round robin, 1 = XCD panel ranges; gemm_split2 (lab):
-                      // column tiles per block of an N-block-major tile order, 0 = N-fastest (what the launcher uses: measured equal or better)
+  int order;          // fp32 pipelined kernel: how the head tiles are dealt - 0 / 2 = round robin, 1 = XCD panel ranges
   // EPI_RANKS_I32: target column of row m = targets ? targets[m] : m + tgt_off (clamped to [0, N)); every workgroup walks `ctw`
   // column tiles of its row block (grid = row blocks x ceil(column tiles / ctw))
   const int32_t* targets;

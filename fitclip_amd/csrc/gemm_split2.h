@@ -135,18 +135,7 @@ __global__ void __launch_bounds__(512) gemm_split2_kernel(const GemmArgs g) {
   }
   __amdgpu_buffer_rsrc_t rsA, rsB;
   auto tile_sources = [&](int tile, int& m0, int& n0) {
-    int tm, tn;
-    if (RR) {
-      tm = tile / tilesN, tn = tile % tilesN;
-    } else if (g.order > 0 && g.order < tnn) {
-      // N-BLOCK-major: for each block of g.order column tiles, every M-panel of the XCD's range - only that block's weight rows are live
-      // in the XCD's L2 at a time, the activation panels are read once per block
-      const int per_block = npanel * g.order, nb = tile / per_block, rem = tile - nb * per_block;
-      const int wb = min(g.order, tnn - nb * g.order);
-      tm = mp0 + rem / wb, tn = tn0 + nb * g.order + rem % wb;
-    } else {
-      tm = mp0 + tile / tnn, tn = tn0 + tile % tnn;
-    }
+    const int tm = RR ? tile / tilesN : mp0 + tile / tnn, tn = RR ? tile % tilesN : tn0 + tile % tnn;
     m0 = tm * BM;
     n0 = tn * BN;
     rot = (tn * (g.nblock > 0 ? g.nblock - 1 : 1)) % nk;

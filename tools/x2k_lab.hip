@@ -168,7 +168,7 @@ int main(int argc, char** argv) {
     const int ns = sh.epi == 1 ? 4 : 0;
     if (sh.epi == 1) {
       vs = {{"m32 shipped", launch_m32<EPI_GELU_X2, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_GELU_X2, 0, 3>, ns},
-            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 spread5 gelu-pairs", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 0>, ns}, {"k32 spread5 gelu-wide plain-split", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 1>, ns}, {"k32 nsplit2 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 2}, {"k32 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1}, {"k32 order3 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1 | (3 << 8)}, {"k32 order4 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1 | (4 << 8)}, {"k32 order2 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1 | (2 << 8)}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
+            {"k32 spread5", launch_k32<EPI_GELU_X2, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_GELU_X2, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_GELU_X2, 0, 5, 4, 2>, ns}, {"k32 spread5 gelu-pairs", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 0>, ns}, {"k32 spread5 gelu-wide plain-split", launch_k32<EPI_GELU_X2, 0, 5, 4, 1, 0, 1>, ns}, {"k32 nsplit2 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 2}, {"k32 nsplit1 spread5", launch_k32<EPI_GELU_X2, 0, 5>, 1}, {"k32 ABL4 stamps pf2", launch_k32<EPI_GELU_X2, 4, 5, 4, 2>, ns},
             {"m32 ABL1 no-loads", launch_m32<EPI_GELU_X2, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_GELU_X2, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_GELU_X2, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_GELU_X2, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_GELU_X2, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_GELU_X2, 6, 3>, ns},
@@ -187,7 +187,6 @@ int main(int argc, char** argv) {
       vs = {{"m32 shipped", launch_m32<EPI_BIAS_F32, 0, 3>, ns}, {"k32 spread3", launch_k32<EPI_BIAS_F32, 0, 3>, ns},
             {"k32 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, ns}, {"k32 spread5 prio1", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 1>, ns}, {"k32 spread5 prio2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 2>, ns}, {"k32 spread5 prio3", launch_k32<EPI_BIAS_F32, 0, 5, 4, 1, 3>, ns}, {"k32 stamps prio1", launch_k32<EPI_BIAS_F32, 4, 5, 4, 1, 1>, ns}, {"k32 stamps prio2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 1, 2>, ns}, {"k32 spread5 pf2", launch_k32<EPI_BIAS_F32, 0, 5, 4, 2>, ns},
             {"k32 ABL4 stamps pf2", launch_k32<EPI_BIAS_F32, 4, 5, 4, 2>, ns}, {"k32 ABL8 two products per line", launch_k32<EPI_BIAS_F32, 8, 5>, ns},
-            {"k32 order3 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, 3 << 8}, {"k32 order1 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, 1 << 8}, {"k32 order5 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, 5 << 8}, {"k32 order0 spread5", launch_k32<EPI_BIAS_F32, 0, 5>, 0},
             {"m32 ABL1 no-loads", launch_m32<EPI_BIAS_F32, 1, 3>, ns}, {"k32 ABL1 no-loads", launch_k32<EPI_BIAS_F32, 1, 3>, ns},
             {"m32 ABL3 no-epilogue", launch_m32<EPI_BIAS_F32, 3, 3>, ns}, {"k32 ABL3 no-epilogue", launch_k32<EPI_BIAS_F32, 3, 3>, ns},
             {"m32 ABL6 mfma only", launch_m32<EPI_BIAS_F32, 6, 3>, ns}, {"k32 ABL6 mfma only", launch_k32<EPI_BIAS_F32, 6, 3>, ns},
@@ -201,8 +200,7 @@ int main(int argc, char** argv) {
     }
     auto args_for = [&](const V& v) {
       GemmArgs b = a;
-      b.nsplit = v.nsplit & 0xff;
-      b.order = v.nsplit >> 8;   // (column tiles per block of the N-block-major tile order; 0 = N-fastest)
+      b.nsplit = v.nsplit;
       return b;
     };
     // correctness first (the residual epilogues add to a zeroed C), then interleaved timing rounds
