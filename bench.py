@@ -842,6 +842,37 @@ def run_wise_config(dims, args, shards, device, backend):
             out["eval_batch_256"] = {"value": round(n / e256, 2), "ms_per_step": round(e256 * 1e3, 3),
                                      "frac_of_fp32_mfma_peak": round(flops / e256 / 1e12 / peak, 4)}
         out["hipgraph"] = graph_leg(enc, module, video, ids, min(bs, n), device)
+        # secondary, never `value`: the same epoch with `precision="fp32x3"` (fp32 results from three fp16 MFMA products per fp32 product:
+        # fc_config.split_gemm = 2) - the reference-shaped call in the mode a user at fp32 tolerance would run
+        enc3 = instantiate(load_encoder_config("wise", {"precision": "fp32x3", "num_frames": frames, "weight_for_2": 0.5}, device)).to(device)
+        enc3.num_frames = frames
+        module3 = TextVideoRetrievalModule(enc3, init_temperature=0.015, n_total=shards.n_total)
+
+        def epoch3():
+            with torch.inference_mode():
+                for s in range(0, n, bs):
+                    module3.validation_step_end(module3.validation_step(
+                        {"video": video[s:s + bs], "text": {"input_ids": ids[s:s + bs]}, "video_id": list(range(s, min(n, s + bs)))}))
+                return module3.validation_epoch_end()   # (asks the range flag: FC_ERANGE if a value left fp16's range)
+
+        for _ in range(max(1, args.warmup)):
+            epoch3()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            metrics3 = epoch3()
+        torch.cuda.synchronize()
+        e3 = (time.perf_counter() - t3) / args.steps
+        k = min(bs, n)
+        with torch.inference_mode():
+            v1, t1_ = enc(video=video[:k], text={"input_ids": ids[:k]})
+            v3, t3_ = enc3(video=video[:k], text={"input_ids": ids[:k]})
+        out["fp32_split_mode"] = {
+            "precision": "fp32x3", "value": round(n / e3, 2), "ms_per_step": round(e3 * 1e3, 3),
+            "speedup_vs_headline": round((elapsed / args.steps) / e3, 3),
+            "metrics": metrics3, "metrics_identical_to_fp32_path": all(metrics3[m] == metrics[m] for m in ("r1", "r5", "r10", "mr")),
+            "embedding_max_abs_vs_fp32_path": {"video": float((v3 - v1).abs().max()), "text": float((t3_ - t1_).abs().max())},
+            "note": "secondary mode, never `value` (see `fp32_split_mode` of the default configuration for its arithmetic)"}
     return out, enc, video, ids
 
 
@@ -988,7 +1019,7 @@ def main() -> None:
                              "arithmetic": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
                              "collectives": collectives, "encoder_build_s (two models + WiSE blend)": w3["encoder_build_s"]},
                   **{k: w3[k] for k in ("roofline", "roofline_all_gemms", "roofline_whole_path", "time_split", "eval_batch_256",
-                                        "hipgraph") if k in w3},
+                                        "hipgraph", "fp32_split_mode") if k in w3},
                   "retrieval": {**{k: v for k, v in w3["metrics"].items()}, "n": n_total, "path": "device, fp32",
                                 "note": "purely random towers: chance-level recall; parity is in cpu_baseline"}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
