@@ -704,6 +704,9 @@ def test_bench_config_c3_wise_evaluate_rehearsal_with_a_ragged_shard():
     assert one["roofline"]["frac"] > 0 and one["roofline_whole_path"]["frac"] > 0 and one["time_split"]["per_gemm"]
     assert one["hipgraph"]["bitwise_equal_to_eager"] is True and one["hipgraph"]["replay_ms"] > 0
     assert "eval_batch_256" not in one
+    split = one["fp32_split_mode"]                     # the same epoch in fp32x3: a secondary leg of the one-rank line
+    assert split["precision"] == "fp32x3" and split["value"] > 0 and split["metrics_identical_to_fp32_path"] is True
+    assert max(split["embedding_max_abs_vs_fp32_path"].values()) < 2e-5 and "fp32_split_mode" not in two
 
 
 def test_bench_config_c5_split_step_rehearsal():
