@@ -459,14 +459,24 @@ def test_other_clip_vit_geometries_match_oracle(tag):
     # the split-fp32 modes serve these geometries too, at the fp32 tolerances: their block GEMMs run on two / three planes whatever
     # the width (1024, 256) and the sequence length; sequence lengths without a fused split attention (50, 257, 577 tokens) take
     # the fp32 attention + a split pass (tools/attn_geometry_probe.py has what that costs)
+    # 40 captions in one call: where the text tower has a width the plane kernels serve (768, 512) and the call has >= 2048 token rows,
+    # fp32x3 runs its block GEMMs on three fp16 products too (the 5-caption call above keeps the fp32 kernels)
+    many = torch.from_numpy(synth.make_text(40, d, seed=13)).to(DEV)
+    many_f32 = None
     for precision in ("fp32", "fp32x6", "fp32x3", "bf16"):
         enc = _encoder(sd, precision)
         enc.num_frames = 2
         got_v = enc.encode_video(torch.from_numpy(video).to(DEV)).cpu().numpy()
         got_t = enc.encode_text({"input_ids": torch.from_numpy(ids).to(DEV)}).cpu().numpy()
+        if precision == "fp32":
+            many_f32 = enc.encode_text({"input_ids": many})
         if precision != "bf16":
             assert np.abs(got_v - ref_v).max() < F32_TOL and np.abs(got_t - ref_t).max() < F32_TOL, precision
             if precision == "fp32x3":
+                got_many = enc.encode_text({"input_ids": many})
+                assert float((got_many - many_f32).abs().max()) < 5e-6, tag
+                joined = d.transformer_width % 256 == 0 and 40 * d.context_length >= 2048
+                assert torch.equal(got_many, many_f32) != joined, tag      # (the other arithmetic exactly where it should be)
                 enc.model.check_range()
         else:
             assert np.abs(got_v - ref_v).max() < BF16_TOL and np.abs(got_t - ref_t).max() < BF16_TOL
